@@ -1,0 +1,278 @@
+#!/usr/bin/env python
+"""Generate golden fixtures from the REFERENCE ITSELF (runs only in the build container).
+
+    python tests/golden/make_golden.py          # writes tests/golden/*.npz
+
+Imports the reference's arch modules from /root/reference/codes (read-only, never copied) with a
+tiny stub for ``utils.util`` (the real one needs cv2/natsort/torchvision), loads
+the seeded parameter recipe (hcflow_amd.params.make_params) into the reference modules with
+``load_state_dict(strict=True)`` -- which also pins our state-dict key/shape table -- and records
+inputs, captured random draws and outputs. Fixtures are DATA only (inputs / expected outputs);
+the GPU box regenerates the weights from the same recipe and checks ``digest``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/codes"
+
+from hcflow_amd.config import NetConfig, preset, param_spec, eps_shapes  # noqa: E402
+from hcflow_amd.params import make_params, param_digest  # noqa: E402
+
+
+def import_reference():
+    from hcflow_amd.config import opt_get
+    utils = types.ModuleType("utils")
+    util = types.ModuleType("utils.util")
+    util.opt_get = opt_get
+    util.register_hook = lambda *a, **k: None
+    util.trunc_normal_ = lambda *a, **k: None
+    utils.util = util
+    sys.modules["utils"] = utils
+    sys.modules["utils.util"] = util
+    sys.path.insert(0, REF)
+    from models.modules.HCFlowNet_SR_arch import HCFlowNet_SR
+    from models.modules.HCFlowNet_Rescaling_arch import HCFlowNet_Rescaling
+    return HCFlowNet_SR, HCFlowNet_Rescaling
+
+
+class Capture:
+    """Record (or replay) torch.normal / torch.rand draws made inside the reference."""
+
+    def __init__(self, replay_normal=None, replay_rand=None):
+        self.normal, self.rand = [], []
+        self.replay_normal = list(replay_normal) if replay_normal is not None else None
+        self.replay_rand = list(replay_rand) if replay_rand is not None else None
+
+    def __enter__(self):
+        self._n, self._r = torch.normal, torch.rand
+
+        def normal(*a, **k):
+            out = self.replay_normal.pop(0) if self.replay_normal is not None else self._n(*a, **k)
+            self.normal.append(out.clone())
+            return out
+
+        def rand(*a, **k):
+            out = self.replay_rand.pop(0) if self.replay_rand is not None else self._r(*a, **k)
+            self.rand.append(out.clone())
+            return out
+
+        torch.normal, torch.rand = normal, rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.normal, torch.rand = self._n, self._r
+
+
+def build(ref_cls, cfg: NetConfig, seed: int):
+    opt = cfg.to_opt()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net = ref_cls(opt=opt, step=0)
+    params = make_params(cfg, seed)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in param_spec(cfg)], "state_dict key ORDER mismatch"
+    for k, shape, _ in param_spec(cfg):
+        assert tuple(sd[k].shape) == tuple(shape), (k, sd[k].shape, shape)
+    net.load_state_dict(params, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net.eval()
+    return net, params
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_net_fixture(name, preset_name, ref_sr, ref_rs, B, h, w, seed, taus=(0.0, 0.8)):
+    cfg = preset(preset_name)
+    net, params = build(ref_sr if cfg.sr else ref_rs, cfg, seed)
+    g = torch.Generator().manual_seed(seed + 17)
+    lr = torch.rand(B, 3, h, w, generator=g)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=g)
+    out = {"preset": preset_name, "seed": seed, "lr": np_(lr), "hr": np_(hr)}
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    with torch.no_grad():
+        for ti, tau in enumerate(taus):
+            with Capture() as cap:
+                y = net(lr=lr, eps_std=tau, reverse=True)
+            eps = cap.normal
+            assert [tuple(e.shape) for e in eps] == eps_shapes(cfg, B, h, w), [e.shape for e in eps]
+            with Capture(replay_normal=eps):
+                y_raw = net.flow(z=lr, eps_std=tau, reverse=True)
+            assert torch.equal(torch.clamp(y_raw, 0, 1), y)
+            out["inv%d_tau" % ti] = np.float64(tau)
+            for i, e in enumerate(eps):
+                out["inv%d_eps%d" % (ti, i)] = np_(e)
+            out["inv%d_out" % ti] = np_(y)
+            out["inv%d_raw" % ti] = np_(y_raw)
+            frac = float(((y_raw < 0) | (y_raw > 1)).float().mean())
+            print("  %s tau=%.1f raw range [%.3f, %.3f] clamped frac %.3f finite %s" % (
+                name, tau, float(y_raw.min()), float(y_raw.max()), frac, bool(torch.isfinite(y_raw).all())))
+            assert torch.isfinite(y_raw).all()
+        if cfg.sr:
+            with Capture() as cap:
+                lr_hat, nll = net(hr=hr, lr=lr, reverse=False)
+            noise = cap.rand[0]
+            # pre-quantisation latent + logdet through the flow (HCFlowNet_SR_arch.py:52-56)
+            pixels = hr.shape[2] * hr.shape[3]
+            x = hr + noise / net.quant
+            logdet0 = torch.zeros_like(hr[:, 0, 0, 0]) + float(-np.log(net.quant) * pixels)
+            z, logdet = net.flow(hr=x, u=None, logdet=logdet0, reverse=False, training=True)
+            out.update(fwd_noise=np_(noise), fwd_lr=np_(lr_hat), fwd_nll=np.float64(float(nll)),
+                       fwd_z=np_(z), fwd_logdet=np_(logdet))
+            # self-consistent case: lr := LR^ (what a trained net sees), same noise replayed
+            with Capture(replay_rand=[noise]):
+                lr_hat2, nll_self = net(hr=hr, lr=lr_hat, reverse=False)
+            assert torch.equal(lr_hat2, lr_hat)
+            out.update(fwd_nll_self=np.float64(float(nll_self)))
+            print("  %s nll %.6f nll_self %.6f logdet %s" % (name, float(nll), float(nll_self), np_(logdet)))
+            assert np.isfinite(float(nll)) and np.isfinite(float(nll_self))
+        else:
+            lr_hat, z1, z2 = net(hr=hr, reverse=False)
+            zraw, _, _ = net.flow(hr=hr, u=None, logdet=None, reverse=False)
+            out.update(fwd_lr=np_(lr_hat), fwd_z1=np_(z1), fwd_z2=np_(z2), fwd_raw=np_(zraw))
+            # round trip as HCFLowRescalingModel.test does (HCFlow_Rescaling_model.py:306-324)
+            from models.modules import Basic
+            lrq = Basic.Quantization()(lr_hat)
+            with Capture() as cap:
+                rt = net(lr=lrq, eps_std=1.0, reverse=True)
+            for i, e in enumerate(cap.normal):
+                out["rt_eps%d" % i] = np_(e)
+            out.update(rt_lrq=np_(lrq), rt_out=np_(rt))
+            print("  %s round-trip PSNR-ish mse %.3e" % (name, float(((rt - hr) ** 2).mean())))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def gen_op_fixture(ref_sr, ref_rs):
+    """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
+    from models.modules import Basic, thops
+    from models.modules.FlowStep import FlowStep
+    from models.modules.ConditionalFlow import ConditionalFlow
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 3, 8, 12, generator=g)
+    out["sq_in"] = np_(x)
+    out["sq_out"] = np_(Basic.squeeze2d(x, 2))
+    y = torch.randn(2, 12, 4, 6, generator=g)
+    out["usq_in"] = np_(y)
+    out["usq_out"] = np_(Basic.unsqueeze2d(y, 2))
+    haar = Basic.HaarDownsampling(3)
+    with torch.no_grad():
+        hf, _ = haar(x, reverse=False)
+        hi, _ = haar(hf, reverse=True)
+        y12 = torch.randn(2, 12, 4, 6, generator=g)
+        hi2, _ = haar(y12, reverse=True)
+    out.update(haar_in=np_(x), haar_fwd=np_(hf), haar_inv_of_fwd=np_(hi), haar_inv_in=np_(y12),
+               haar_inv_out=np_(hi2))
+    # split_feature on odd C
+    z21 = torch.randn(2, 21, 4, 4, generator=g)
+    a, b = thops.split_feature(z21, "split")
+    c, d = thops.split_feature(z21, "cross")
+    out.update(split_in=np_(z21), split_a=np_(a), split_b=np_(b), cross_a=np_(c), cross_b=np_(d))
+    # GaussianDiag
+    mean = torch.randn(2, 6, 4, 4, generator=g)
+    logs = torch.randn(2, 6, 4, 4, generator=g) * 0.3
+    xx = torch.randn(2, 6, 4, 4, generator=g)
+    out.update(g_mean=np_(mean), g_logs=np_(logs), g_x=np_(xx),
+               g_logp=np_(Basic.GaussianDiag.logp(mean, logs, xx)))
+    # Quant
+    q = torch.randn(2, 3, 5, 5, generator=g) * 0.7 + 0.5
+    out.update(q_in=np_(q), q_out=np_(Basic.Quantization()(q)))
+    # ActNorm data init (training mode, fresh module)
+    from models.modules.ActNorms import ActNorm2d
+    an = ActNorm2d(5)
+    an.train()
+    xi = torch.randn(4, 5, 6, 6, generator=g) * 2 + 1
+    with torch.no_grad():
+        yo, _ = an(xi)
+    out.update(ani_in=np_(xi), ani_bias=np_(an.bias), ani_logs=np_(an.logs), ani_out=np_(yo))
+    np.savez_compressed(os.path.join(HERE, "ops_index.npz"), **out)
+
+    # FlowStep / ConditionalFlow pins use the seeded recipe on a tiny SR net so that the
+    # parameters come from make_params (regenerable) -- take sub-modules of the loaded net.
+    cfg = preset("SR_4X_tiny")
+    net, params = build(ref_sr, cfg, 4321)
+    o2 = {"preset": "SR_4X_tiny", "seed": 4321}
+    with torch.no_grad():
+        # unconditional FlowStep at level 0: flow.layers.1 (C=12)
+        fs = net.flow.layers[1]
+        z = torch.randn(2, 12, 6, 10, generator=g)
+        ld0 = torch.zeros(2)
+        zf, ld = fs(z, None, logdet=ld0.clone(), reverse=False)
+        zi, _ = fs(zf, None, reverse=True)
+        o2.update(fs_in=np_(z), fs_fwd=np_(zf), fs_logdet=np_(ld), fs_inv_of_fwd=np_(zi))
+        # FCN inside it
+        f = fs.affine.f
+        z1 = torch.randn(2, 6, 6, 10, generator=g)
+        o2.update(fcn_in=np_(z1), fcn_out=np_(f(z1)))
+        # conditional FlowStep of level1_condFlow (C=21, cond 128)
+        cfl = net.flow.level1_condFlow
+        cs = cfl.additional_flow_steps[0]
+        zc = torch.randn(2, 21, 5, 7, generator=g)
+        u = torch.randn(2, 128, 5, 7, generator=g) * 0.5
+        zcf, ldc = cs(zc, u, logdet=torch.zeros(2), reverse=False)
+        zci, _ = cs(zcf, u, reverse=True)
+        o2.update(cs_in=np_(zc), cs_u=np_(u), cs_fwd=np_(zcf), cs_logdet=np_(ldc), cs_inv_of_fwd=np_(zci))
+        # RDB / RRDB / cond features
+        r = cfl.RRDB_trunk0[0]
+        xr = torch.randn(2, 64, 5, 7, generator=g) * 0.5
+        o2.update(rrdb_in=np_(xr), rdb_out=np_(r.RDB1(xr)), rrdb_out=np_(r(xr)))
+        lr = torch.rand(2, 3, 5, 7, generator=g)
+        o2.update(cf_in=np_(lr), cf_out=np_(cfl.get_conditional_feature_SR(lr)))
+        # prior head
+        h = cfl.f(u)
+        o2.update(head_out=np_(h))
+    np.savez_compressed(os.path.join(HERE, "ops_sr_tiny.npz"), **o2)
+
+    cfg = preset("Rescaling_4X_tiny")
+    net, params = build(ref_rs, cfg, 4322)
+    o3 = {"preset": "Rescaling_4X_tiny", "seed": 4322}
+    with torch.no_grad():
+        for name, idx in (("even", 1), ("odd", 2)):       # LRvsothers True / False
+            fs = net.flow.layers[idx]
+            z = torch.randn(2, 12, 6, 10, generator=g)
+            zf, _ = fs(z, None, reverse=False)
+            zi, _ = fs(zf, None, reverse=True)
+            o3.update({"fs_%s_in" % name: np_(z), "fs_%s_fwd" % name: np_(zf),
+                       "fs_%s_inv_of_fwd" % name: np_(zi)})
+            db = fs.affine.f
+            cin = db.conv1.weight.shape[1]
+            xd = torch.randn(2, cin, 6, 10, generator=g)
+            o3.update({"db_%s_in" % name: np_(xd), "db_%s_out" % name: np_(db(xd))})
+        cfl = net.flow.level1_condFlow
+        lr = torch.rand(2, 3, 5, 7, generator=g)
+        o3.update(cf_in=np_(lr), cf_out=np_(cfl.get_conditional_feature_Rescaling(lr)))
+    np.savez_compressed(os.path.join(HERE, "ops_rescaling_tiny.npz"), **o3)
+    print("wrote op fixtures")
+
+
+def main():
+    torch.set_num_threads(8)
+    ref_sr, ref_rs = import_reference()
+    gen_op_fixture(ref_sr, ref_rs)
+    # reduced-depth nets with the real channel widths, odd-ish spatial sizes, B=2
+    gen_net_fixture("net_sr4_tiny", "SR_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=11)
+    gen_net_fixture("net_sr8_tiny", "SR_8X_tiny", ref_sr, ref_rs, B=2, h=5, w=6, seed=12)
+    gen_net_fixture("net_rescale_tiny", "Rescaling_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=13,
+                    taus=(0.0, 1.0))
+    # full-depth shipped configs on a small patch, B=1
+    gen_net_fixture("net_sr4_full", "SR_DF2K_4X", ref_sr, ref_rs, B=1, h=8, w=8, seed=21)
+    gen_net_fixture("net_sr8_full", "SR_CelebA_8X", ref_sr, ref_rs, B=1, h=4, w=4, seed=22)
+    gen_net_fixture("net_rescale_full", "Rescaling_DF2K_4X", ref_sr, ref_rs, B=1, h=8, w=8, seed=23,
+                    taus=(0.0, 1.0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz).
+
+Tolerances: index ops bit-exact; elementwise 1e-6; conv stacks 1e-5;
+end-to-end 1e-4 abs (fp32 noise floor of the reference measured at 4.5e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcflow_oracle as O
+from tests.util import load_golden, params_for, t, maxdiff
+
+
+def test_index_ops_bit_exact():
+    g = load_golden("ops_index")
+    assert torch.equal(O.squeeze2d(t(g["sq_in"])), t(g["sq_out"]))
+    assert torch.equal(O.unsqueeze2d(t(g["usq_in"])), t(g["usq_out"]))
+    assert torch.equal(O.unsqueeze2d(O.squeeze2d(t(g["sq_in"]))), t(g["sq_in"]))
+    a, b = O.split_half(t(g["split_in"]))
+    c, d = O.split_cross(t(g["split_in"]))
+    assert a.shape[1] == 10 and b.shape[1] == 11          # odd C: 21 -> (10, 11)
+    assert torch.equal(a, t(g["split_a"])) and torch.equal(b, t(g["split_b"]))
+    assert torch.equal(c, t(g["cross_a"])) and torch.equal(d, t(g["cross_b"]))
+    assert torch.equal(O.quantize(t(g["q_in"])), t(g["q_out"]))
+
+
+def test_haar():
+    g = load_golden("ops_index")
+    assert maxdiff(O.haar_forward(t(g["haar_in"])), g["haar_fwd"]) <= 1e-6
+    assert maxdiff(O.haar_inverse(t(g["haar_inv_in"])), g["haar_inv_out"]) <= 1e-6
+    assert maxdiff(O.haar_inverse(O.haar_forward(t(g["haar_in"]))), g["haar_in"]) <= 1e-6
+
+
+def test_gaussian_and_actnorm_init():
+    g = load_golden("ops_index")
+    lp = O.gaussian_logp(t(g["g_mean"]), t(g["g_logs"]), t(g["g_x"]))
+    assert maxdiff(lp, g["g_logp"]) <= 1e-4 * max(1.0, float(np.abs(g["g_logp"]).max()))
+    b, s = O.actnorm_data_init(t(g["ani_in"]))
+    assert maxdiff(b, g["ani_bias"]) <= 1e-6 and maxdiff(s, g["ani_logs"]) <= 1e-6
+    assert maxdiff(O.actnorm_forward(t(g["ani_in"]), b, s), g["ani_out"]) <= 1e-5
+
+
+def test_sr_ops():
+    g = load_golden("ops_sr_tiny")
+    cfg, p = params_for(g)
+    pre = "flow.layers.1"
+    z, ld = O.flowstep_forward(t(g["fs_in"]), None, torch.zeros(2), p, pre, "invconv", "Affine", "FCN")
+    assert maxdiff(z, g["fs_fwd"]) <= 1e-5
+    assert maxdiff(ld, g["fs_logdet"]) <= 1e-3
+    zi = O.flowstep_inverse(t(g["fs_fwd"]), None, p, pre, "invconv", "Affine", "FCN")
+    assert maxdiff(zi, g["fs_inv_of_fwd"]) <= 1e-5
+    assert maxdiff(zi, g["fs_in"]) <= 1e-4
+    assert maxdiff(O.fcn(t(g["fcn_in"]), p, pre + ".affine.f"), g["fcn_out"]) <= 1e-5
+    cpre = "flow.level1_condFlow"
+    spre = cpre + ".additional_flow_steps.0"
+    z, ld = O.flowstep_forward(t(g["cs_in"]), t(g["cs_u"]), torch.zeros(2), p, spre, "invconv", "Affine", "FCN")
+    assert maxdiff(z, g["cs_fwd"]) <= 1e-5 and maxdiff(ld, g["cs_logdet"]) <= 1e-3
+    zi = O.flowstep_inverse(t(g["cs_fwd"]), t(g["cs_u"]), p, spre, "invconv", "Affine", "FCN")
+    assert maxdiff(zi, g["cs_inv_of_fwd"]) <= 1e-5
+    assert maxdiff(O.rdb(t(g["rrdb_in"]), p, cpre + ".RRDB_trunk0.0.RDB1"), g["rdb_out"]) <= 1e-5
+    assert maxdiff(O.rrdb(t(g["rrdb_in"]), p, cpre + ".RRDB_trunk0.0"), g["rrdb_out"]) <= 1e-5
+    assert maxdiff(O.cond_features(t(g["cf_in"]), p, cpre, cfg), g["cf_out"]) <= 1e-5
+    assert maxdiff(O.conv_zeros(t(g["cs_u"]), p, cpre + ".f"), g["head_out"]) <= 1e-5
+
+
+def test_rescaling_ops():
+    g = load_golden("ops_rescaling_tiny")
+    cfg, p = params_for(g)
+    for name, idx, lrv in (("even", 1, True), ("odd", 2, False)):
+        pre = "flow.layers.%d" % idx
+        z, _ = O.flowstep_forward(t(g["fs_%s_in" % name]), None, None, p, pre, "none", "Affine3shift",
+                                  "DenseBlock", lrv)
+        assert maxdiff(z, g["fs_%s_fwd" % name]) <= 1e-5
+        zi = O.flowstep_inverse(t(g["fs_%s_fwd" % name]), None, p, pre, "none", "Affine3shift",
+                                "DenseBlock", lrv)
+        assert maxdiff(zi, g["fs_%s_inv_of_fwd" % name]) <= 1e-5
+        assert maxdiff(O.dense5(t(g["db_%s_in" % name]), p, pre + ".affine.f"), g["db_%s_out" % name]) <= 1e-5
+    assert maxdiff(O.cond_features(t(g["cf_in"]), p, "flow.level1_condFlow", cfg), g["cf_out"]) <= 1e-5
+
+
+NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full"]
+NETS_RS = ["net_rescale_tiny", "net_rescale_full"]
+
+
+def _eps(g, pre):
+    out = []
+    i = 0
+    while "%s_eps%d" % (pre, i) in g.files:
+        out.append(t(g["%s_eps%d" % (pre, i)]))
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("name", NETS_SR + NETS_RS)
+def test_net_inverse(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    inv = O.sr_inverse if cfg.sr else O.rescale_inverse
+    with torch.no_grad():
+        for ti in (0, 1):
+            tau = float(g["inv%d_tau" % ti])
+            eps = _eps(g, "inv%d" % ti)
+            raw = inv(t(g["lr"]), p, cfg, tau, eps, clamp=False)
+            scale = max(1.0, float(np.abs(g["inv%d_raw" % ti]).max()))
+            assert maxdiff(raw, g["inv%d_raw" % ti]) <= 1e-4 * scale, (name, ti)
+            out = inv(t(g["lr"]), p, cfg, tau, eps)
+            assert maxdiff(out, g["inv%d_out" % ti]) <= 1e-4
+
+
+@pytest.mark.parametrize("name", NETS_SR)
+def test_sr_forward_nll(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    with torch.no_grad():
+        lr_hat, nll = O.sr_forward(t(g["hr"]), t(g["lr"]), p, cfg, noise=t(g["fwd_noise"]))
+        # quantised output: allow a single 1/255 flip where the pre-quant value sits on a rounding edge
+        d = (lr_hat - t(g["fwd_lr"])).abs()
+        assert float(d.max()) <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 0.01
+        _, nll_self = O.sr_forward(t(g["hr"]), t(g["fwd_lr"]), p, cfg, noise=t(g["fwd_noise"]))
+        assert abs(float(nll_self) - float(g["fwd_nll_self"])) <= 1e-4, (float(nll_self), float(g["fwd_nll_self"]))
+        assert abs(float(nll) - float(g["fwd_nll"])) <= 1e-5 * abs(float(g["fwd_nll"]))
+        # pre-quantisation latent and log-det
+        H, W = g["hr"].shape[2:]
+        x = t(g["hr"]) + t(g["fwd_noise"]) / cfg.quant
+        ld0 = torch.zeros(x.shape[0]) + float(-np.log(cfg.quant) * H * W)
+        z, ld, _ = O.flownet_forward(x, ld0, p, cfg)
+        assert maxdiff(z, g["fwd_z"]) <= 1e-4
+        assert maxdiff(ld, g["fwd_logdet"]) <= 1e-5 * float(np.abs(g["fwd_logdet"]).max())
+
+
+@pytest.mark.parametrize("name", NETS_RS)
+def test_rescale_forward_roundtrip(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    with torch.no_grad():
+        lr_hat, z1, z2 = O.rescale_forward(t(g["hr"]), p, cfg)
+        assert maxdiff(lr_hat, g["fwd_lr"]) <= 1e-4
+        assert maxdiff(z1, g["fwd_z1"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z1"]).max()))
+        assert maxdiff(z2, g["fwd_z2"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z2"]).max()))
+        rt = O.rescale_inverse(t(g["rt_lrq"]), p, cfg, 1.0, _eps(g, "rt"))
+        assert maxdiff(rt, g["rt_out"]) <= 1e-4
