@@ -1,0 +1,175 @@
+"""ctypes binding of libhcflow_hip.so (the C ABI declared in include/hcflow.h).
+
+There is no fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhcflow_hip.so")
+
+HCF_OK = 0
+ERR_NAMES = {-1: "HCF_ERR_ARG", -2: "HCF_ERR_HIP", -3: "HCF_ERR_STATE", -4: "HCF_ERR_KEY",
+             -5: "HCF_ERR_SHAPE", -6: "HCF_ERR_UNSUPPORTED", -7: "HCF_ERR_NOMEM"}
+FLAG_NO_CLAMP = 1
+
+# every symbol include/hcflow.h declares (tests/test_cabi_cpu.py checks the .so exports them all)
+SYMBOLS = [
+    "hcf_create", "hcf_destroy", "hcf_last_error", "hcf_param_count", "hcf_param_info",
+    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_forward_sr", "hcf_forward_rescale",
+    "hcf_workspace_bytes", "hcf_weight_bytes", "hcf_profile_convs", "hcf_conv_time_ms",
+    "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
+    "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
+    "hcf_op_gauss_sample",
+]
+
+
+class HcfError(RuntimeError):
+    pass
+
+
+class hcf_config(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("scale", C.c_int32), ("in_nc", C.c_int32), ("quant", C.c_float),
+        ("L", C.c_int32), ("K", C.c_int32 * 4), ("after", C.c_int32 * 4), ("squeeze", C.c_int32),
+        ("perm", C.c_int32), ("coupling", C.c_int32), ("nn_module", C.c_int32), ("hidden", C.c_int32),
+        ("c_perm", C.c_int32), ("c_coupling", C.c_int32), ("c_nn_module", C.c_int32), ("c_hidden", C.c_int32),
+        ("rrdb_nb", C.c_int32 * 2), ("rrdb_nf", C.c_int32), ("rrdb_gc", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HcfError(
+            "libhcflow_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C hcflow_amd/csrc`). hcflow_amd has no CPU/PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+    fp = C.c_void_p          # device / host float pointers travel as raw addresses
+    lib.hcf_create.argtypes = [C.POINTER(hcf_config), C.POINTER(vp)]
+    lib.hcf_destroy.argtypes = [vp]
+    lib.hcf_destroy.restype = None
+    lib.hcf_last_error.argtypes = [vp]
+    lib.hcf_last_error.restype = C.c_char_p
+    lib.hcf_param_count.argtypes = [vp]
+    lib.hcf_param_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(i32), C.POINTER(i64)]
+    lib.hcf_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.hcf_finalize.argtypes = [vp, C.c_int]
+    lib.hcf_inverse.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, fp, i32, i32, i32, u32, vp]
+    lib.hcf_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
+    lib.hcf_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, u32, vp]
+    lib.hcf_workspace_bytes.argtypes = [vp]
+    lib.hcf_workspace_bytes.restype = C.c_size_t
+    lib.hcf_weight_bytes.argtypes = [vp]
+    lib.hcf_weight_bytes.restype = C.c_size_t
+    lib.hcf_profile_convs.argtypes = [vp, C.c_int]
+    lib.hcf_conv_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
+                                  i32, i32, i32, fp, f32, fp, f32, fp, vp]
+    lib.hcf_op_squeeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.hcf_op_unsqueeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.hcf_op_step_inverse.argtypes = [fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, fp, vp]
+    lib.hcf_op_step_forward_head.argtypes = [fp, fp, i32, i32, i32, i32, fp, fp, fp, vp]
+    lib.hcf_op_step_forward_couple.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.hcf_op_gauss_logp.argtypes = [fp, fp, fp, i32, i32, i32, i32, vp]
+    lib.hcf_op_gauss_sample.argtypes = [fp, fp, f32, u64, fp, i32, i32, i32, i32, i32, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("hcf_destroy", "hcf_last_error", "hcf_workspace_bytes", "hcf_weight_bytes"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, engine=None, what: str = ""):
+    if rc == HCF_OK:
+        return
+    msg = ""
+    if engine is not None:
+        m = load().hcf_last_error(engine)
+        msg = m.decode() if m else ""
+    raise HcfError("%s failed: %s (%d) %s" % (what or "hcflow call", ERR_NAMES.get(rc, "?"), rc, msg))
+
+
+def make_config(cfg) -> hcf_config:
+    """hcflow_amd.config.NetConfig -> C struct."""
+    c = hcf_config()
+    c.kind = 0 if cfg.sr else 1
+    c.scale = cfg.scale
+    c.in_nc = cfg.in_nc
+    c.quant = float(cfg.quant)
+    c.L = cfg.L
+    for i in range(4):
+        c.K[i] = cfg.K[i] if i < len(cfg.K) else 0
+        c.after[i] = cfg.after[i] if i < len(cfg.after) else 0
+    c.squeeze = 1 if cfg.squeeze == "haar" else 0
+    perm = {"invconv": 0, "none": 1}
+    cpl = {"Affine": 0, "Affine3shift": 1}
+    nn = {"FCN": 0, "DenseBlock": 1}
+    c.perm, c.coupling, c.nn_module, c.hidden = perm[cfg.perm], cpl[cfg.coupling], nn[cfg.nn_module], cfg.hidden
+    c.c_perm, c.c_coupling, c.c_nn_module, c.c_hidden = (perm[cfg.c_perm], cpl[cfg.c_coupling],
+                                                         nn[cfg.c_nn_module], cfg.c_hidden)
+    c.rrdb_nb[0], c.rrdb_nb[1] = cfg.rrdb_nb
+    c.rrdb_nf, c.rrdb_gc = cfg.rrdb_nf, cfg.rrdb_gc
+    return c
+
+
+class Engine:
+    """Owning handle around hcf_engine*."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        c = make_config(cfg)
+        check(self.lib.hcf_create(C.byref(c), C.byref(self._h)), None, "hcf_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h:
+                self.lib.hcf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def param_spec(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        n = self.lib.hcf_param_count(self._h)
+        out = []
+        key = C.c_char_p()
+        nd = C.c_int32()
+        shape = (C.c_int64 * 4)()
+        for i in range(n):
+            check(self.lib.hcf_param_info(self._h, i, C.byref(key), C.byref(nd), shape), self._h, "hcf_param_info")
+            out.append((key.value.decode(), tuple(int(shape[j]) for j in range(nd.value))))
+        return out
+
+    def set_param(self, key: str, host_tensor):
+        """host_tensor: contiguous fp32 CPU torch tensor."""
+        t = host_tensor
+        assert t.device.type == "cpu" and t.is_contiguous() and str(t.dtype) == "torch.float32", key
+        shape = (C.c_int64 * 4)(*([int(s) for s in t.shape] + [1] * (4 - t.dim())))
+        check(self.lib.hcf_set_param(self._h, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()), self._h,
+              "hcf_set_param(%s)" % key)
+
+    def finalize(self, device: int):
+        check(self.lib.hcf_finalize(self._h, int(device)), self._h, "hcf_finalize")
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.hcf_workspace_bytes(self._h))
+
+    def weight_bytes(self) -> int:
+        return int(self.lib.hcf_weight_bytes(self._h))

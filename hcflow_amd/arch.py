@@ -1,0 +1,415 @@
+"""Drop-in architecture classes: the reference's module surface over the MI355X engine.
+
+``codes/models/networks.py:36-41`` (define_G) instantiates ``HCFlowNet_SR(opt=opt, step=step)`` /
+``HCFlowNet_Rescaling(opt=opt, step=step)`` and the model wrappers call
+``netG(hr=, lr=, z=, u=, eps_std=, add_gt_noise=, step=, reverse=, training=)`` by keyword
+(HCFlow_SR_model.py:195,208,305,311; HCFlow_Rescaling_model.py:214,219,312,319). The classes here
+keep that surface:
+
+* same constructor, same ``forward`` signature and return values
+  (HCFlowNet_SR_arch.py:34-75, HCFlowNet_Rescaling_arch.py:26-54);
+* an ``nn.Module`` tree whose ``state_dict()`` keys / shapes / order equal the reference's, so
+  ``load_network(strict=True)`` (base_model.py:96-120) works on released checkpoints;
+* ``named_modules()`` yields ``*ActNorm*`` modules with a writable ``.inited``
+  (HCFlow_SR_model.py:462-465).
+
+The modules below only HOLD parameters; all arithmetic runs in hand-written HIP kernels behind the
+C ABI of ``include/hcflow.h`` (``libhcflow_hip.so``). There is no PyTorch fallback: without the
+library or without a GPU, ``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import NetConfig, coupling_io, eps_shapes, opt_get, param_spec
+
+
+# ------------------------------------------------------------------ parameter containers
+def _xavier(shape, scale=0.1):
+    w = torch.empty(*shape)
+    nn.init.xavier_normal_(w)          # mutil.initialize_weights_xavier (module_util.py:26-43)
+    return nn.Parameter(w * scale)
+
+
+class ActNorm2d(nn.Module):
+    """Parameters of ActNorms.ActNorm2d (ActNorms.py:7-27): bias, logs [1,C,1,1] + ``inited``."""
+
+    def __init__(self, num_features, scale=1.):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(1, num_features, 1, 1))
+        self.logs = nn.Parameter(torch.zeros(1, num_features, 1, 1))
+        self.num_features = num_features
+        self.scale = float(scale)
+        self.inited = False
+
+
+class InvertibleConv1x1(nn.Module):
+    """Permutations.InvertibleConv1x1, LU_decomposed=False (Permutations.py:33-40): random orthogonal init."""
+
+    def __init__(self, num_channels):
+        super().__init__()
+        w_init = np.linalg.qr(np.random.randn(num_channels, num_channels))[0].astype(np.float32)
+        self.weight = nn.Parameter(torch.from_numpy(w_init))
+
+
+class Conv2d(nn.Module):
+    """Basic.Conv2d with do_actnorm=True (Basic.py:14-53): bias-free conv weight + ActNorm2d."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = _xavier((cout, cin, k, k))
+        self.actnorm = ActNorm2d(cout)
+
+
+class Conv2dZeros(nn.Module):
+    """Basic.Conv2dZeros (Basic.py:57-72): zero-initialised weight, bias, logs [cout,1,1]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.logs = nn.Parameter(torch.zeros(cout, 1, 1))
+
+
+class PlainConv(nn.Module):
+    """nn.Conv2d(cin, cout, 3, 1, 1, bias=True) parameters."""
+
+    def __init__(self, cin, cout, init="xavier"):
+        super().__init__()
+        if init == "xavier":
+            self.weight = _xavier((cout, cin, 3, 3))
+            self.bias = nn.Parameter(torch.zeros(cout))
+        elif init == "zero":
+            self.weight = nn.Parameter(torch.zeros(cout, cin, 3, 3))
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:                                   # torch's default Conv2d reset_parameters
+            ref = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+            self.weight = nn.Parameter(ref.weight.detach().clone())
+            self.bias = nn.Parameter(ref.bias.detach().clone())
+
+
+class FCN(nn.Module):
+    """Basic.FCN (Basic.py:426-447)."""
+
+    def __init__(self, cin, cout, hidden):
+        super().__init__()
+        self.conv1 = Conv2d(cin, hidden, 3)
+        self.conv2 = Conv2d(hidden, hidden, 1)
+        self.conv3 = Conv2dZeros(hidden, cout)
+
+
+class DenseBlock(nn.Module):
+    """Basic.DenseBlock, for_flow=True (Basic.py:329-347): conv5 zero-initialised."""
+
+    def __init__(self, cin, cout, gc):
+        super().__init__()
+        for i in range(4):
+            setattr(self, "conv%d" % (i + 1), PlainConv(cin + i * gc, gc))
+        self.conv5 = PlainConv(cin + 4 * gc, cout, init="zero")
+
+
+class ResidualDenseBlock(nn.Module):
+    """Basic.ResidualDenseBlock (Basic.py:360-377)."""
+
+    def __init__(self, nf, gc):
+        super().__init__()
+        for i in range(4):
+            setattr(self, "conv%d" % (i + 1), PlainConv(nf + i * gc, gc))
+        self.conv5 = PlainConv(nf + 4 * gc, nf)
+
+
+class RRDB(nn.Module):
+    """Basic.RRDB (Basic.py:387-392)."""
+
+    def __init__(self, nf, gc):
+        super().__init__()
+        self.RDB1 = ResidualDenseBlock(nf, gc)
+        self.RDB2 = ResidualDenseBlock(nf, gc)
+        self.RDB3 = ResidualDenseBlock(nf, gc)
+
+
+class AffineCoupling(nn.Module):
+    """AffineCouplings.AffineCoupling / AffineCoupling3shift parameter holder (``f``)."""
+
+    def __init__(self, C, cond, coupling, nn_module, hidden, lr_vs_others=True):
+        super().__init__()
+        fin, fout = coupling_io(C, cond, coupling, lr_vs_others)
+        self.f = FCN(fin, fout, hidden) if nn_module == "FCN" else DenseBlock(fin, fout, hidden)
+
+
+class FlowStep(nn.Module):
+    """FlowStep (FlowStep.py:8-38): actnorm, permute, affine."""
+
+    def __init__(self, C, cond, perm, coupling, nn_module, hidden, lr_vs_others=True):
+        super().__init__()
+        self.actnorm = ActNorm2d(C)
+        if perm == "invconv":
+            self.permute = InvertibleConv1x1(C)
+        else:
+            self.permute = None
+        self.affine = AffineCoupling(C, cond, coupling, nn_module, hidden, lr_vs_others)
+
+
+class SqueezeLayer(nn.Module):
+    def __init__(self, factor=2):
+        super().__init__()
+        self.factor = factor
+
+
+class HaarDownsampling(nn.Module):
+    """Basic.HaarDownsampling (Basic.py:450-468): frozen +-1 ``haar_weights`` parameter."""
+
+    def __init__(self, channel_in):
+        super().__init__()
+        w = torch.ones(4, 1, 2, 2)
+        w[1, 0, 0, 1] = -1
+        w[1, 0, 1, 1] = -1
+        w[2, 0, 1, 0] = -1
+        w[2, 0, 1, 1] = -1
+        w[3, 0, 1, 0] = -1
+        w[3, 0, 0, 1] = -1
+        self.haar_weights = nn.Parameter(torch.cat([w] * channel_in, 0), requires_grad=False)
+
+
+class Split(nn.Module):
+    def __init__(self, num_channels_split, level):
+        super().__init__()
+        self.num_channels_split = num_channels_split
+        self.level = level
+
+
+class ConditionalFlow(nn.Module):
+    """ConditionalFlow (ConditionalFlow.py:15-41)."""
+
+    def __init__(self, cfg: NetConfig, level: int):
+        super().__init__()
+        C, ns = cfg.level_channels(level), cfg.split_channels(level)
+        cin = ns + cfg.cond_ch * cfg.num_levels_condition(level)
+        self.conv_first = PlainConv(cin, cfg.rrdb_nf, init="default")
+        self.RRDB_trunk0 = nn.Sequential(*[RRDB(cfg.rrdb_nf, cfg.rrdb_gc) for _ in range(cfg.rrdb_nb[0])])
+        self.RRDB_trunk1 = nn.Sequential(*[RRDB(cfg.rrdb_nf, cfg.rrdb_gc) for _ in range(cfg.rrdb_nb[1])])
+        self.trunk_conv1 = PlainConv(cfg.rrdb_nf, cfg.rrdb_nf, init="default")
+        self.additional_flow_steps = nn.ModuleList(
+            [FlowStep(C - ns, cfg.cond_ch, cfg.c_perm, cfg.c_coupling, cfg.c_nn_module, cfg.c_hidden)
+             for _ in range(cfg.after[level])])
+        self.f = Conv2dZeros(cfg.cond_ch, (C - ns) * 2)
+
+
+class FlowNet(nn.Module):
+    """FlowNet.__init__ of FlowNet_SR_x4 / FlowNet_SR_x8 / FlowNet_Rescaling_x4 (layer list only)."""
+
+    def __init__(self, cfg: NetConfig, hr_size: int = 160):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.output_shapes = []
+        H = W = hr_size
+        C = cfg.in_nc
+        for level in range(cfg.L):
+            self.layers.append(HaarDownsampling(C) if cfg.squeeze == "haar" else SqueezeLayer(2))
+            C, H, W = C * 4, H // 2, W // 2
+            self.output_shapes.append([-1, C, H, W])
+            for k in range(cfg.K[level] - cfg.after[level]):
+                lrv = True if cfg.sr else (k % 2 == 0)
+                self.layers.append(FlowStep(C, 0, cfg.perm, cfg.coupling, cfg.nn_module, cfg.hidden, lrv))
+                self.output_shapes.append([-1, C, H, W])
+            ns = cfg.split_channels(level)
+            self.layers.append(Split(ns, level))
+            setattr(self, "level%d_condFlow" % level, ConditionalFlow(cfg, level))
+            C = ns
+            self.output_shapes.append([-1, C, H, W])
+        self.H, self.W = H, W
+        print('shapes:', self.output_shapes)      # FlowNet_SR_x4.py:71
+
+
+# ------------------------------------------------------------------ engine-backed top modules
+class _EngineModule(nn.Module):
+    """Shared plumbing: parameter upload / repack tracking and raw-pointer calls into the C ABI."""
+
+    def _setup(self, opt):
+        self.opt = opt
+        self.cfg = NetConfig.from_opt(opt)
+        hr_size = opt_get(opt, ['datasets', 'train', 'GT_size'], 160)
+        self.flow = FlowNet(self.cfg, hr_size)
+        spec = [(k, tuple(s)) for k, s, _ in param_spec(self.cfg)]
+        have = [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
+        assert have == spec, "internal: module tree does not match the reference state_dict table"
+        # engines are per device (nn.DataParallel replicas share this dict but not the entries)
+        object.__setattr__(self, "_engines", {})
+
+    # -- engine management
+    def _engine_for(self, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.HcfError(
+                "hcflow_amd runs on MI355X only: move the module and its inputs to a GPU "
+                "(module parameters are on %s). There is no CPU fallback." % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        ent = self._engines.get(idx)
+        if ent is None:
+            ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
+            self._engines[idx] = ent
+        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if ent["stamp"] != stamp:
+            eng = ent["engine"]
+            sd = self.state_dict()
+            for key, t in sd.items():
+                eng.set_param(key, t.detach().to("cpu", torch.float32).contiguous())
+            eng.finalize(idx)
+            ent["stamp"] = stamp
+        return ent["engine"], idx
+
+    def _check_inference(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "hcflow_amd round 1 implements the forward/inverse inference path; the backward pass "
+                "(train_HCFlow.py optimize_parameters) is SURVEY.md section 8f rank 1. Call under torch.no_grad().")
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, ActNorm2d) and not m.inited:
+                    raise NotImplementedError(
+                        "ActNorm data-dependent initialisation (ActNorms.py:29-43) belongs to the training "
+                        "path (SURVEY.md 8f rank 1); load a checkpoint / set .inited = True or call .eval().")
+
+    @staticmethod
+    def _prep(t: torch.Tensor, device) -> torch.Tensor:
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def _stream(idx):
+        return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+
+    def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None):
+        self._check_inference()
+        dev = next(self.parameters()).device
+        eng, idx = self._engine_for(dev)
+        lr = self._prep(lr, dev)
+        B, c, h, w = lr.shape
+        assert c == 3
+        cfg = self.cfg
+        out = torch.empty(B, 3, h * cfg.scale, w * cfg.scale, device=dev, dtype=torch.float32)
+        shapes = eps_shapes(cfg, B, h, w)
+        keep = []
+        arr = (C.c_void_p * len(shapes))()
+        if eps is not None:
+            assert len(eps) == len(shapes)
+            for i, (e, s) in enumerate(zip(eps, shapes)):
+                if e is None:
+                    arr[i] = None
+                    continue
+                e = self._prep(e, dev)
+                assert tuple(e.shape) == tuple(s), (tuple(e.shape), s)
+                keep.append(e)
+                arr[i] = e.data_ptr()
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
+        tau = 0.0 if eps_std is None else float(eps_std)
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_inverse(eng.handle, lr.data_ptr(), arr, len(shapes), tau, seed, out.data_ptr(),
+                                     B, h, w, 0 if clamp else _lib.FLAG_NO_CLAMP, self._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_inverse")
+        return out
+
+    # convenience for benchmarks / multi-GPU sharding
+    def engine(self):
+        dev = next(self.parameters()).device
+        return self._engine_for(dev)[0]
+
+
+class HCFlowNet_SR(_EngineModule):
+    """Drop-in for models.modules.HCFlowNet_SR_arch.HCFlowNet_SR (HCFlowNet_SR_arch.py:11-75)."""
+
+    def __init__(self, opt, step=None):
+        super(HCFlowNet_SR, self).__init__()
+        self.quant = opt_get(opt, ['quant'], 256)
+        self._setup(opt)
+        assert self.cfg.sr
+
+    # hr: HR image, lr: LR image, z: latent variable, u: conditional variable
+    def forward(self, hr=None, lr=None, z=None, u=None, eps_std=None,
+                add_gt_noise=False, step=None, reverse=False, training=True, eps=None, noise=None):
+        if not reverse:
+            return self.normal_flow_diracLR(hr, lr, u, step=step, training=training, noise=noise)
+        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps)
+
+    def normal_flow_diracLR(self, hr, lr, u=None, step=None, training=True, noise=None, return_internals=False):
+        """hr -> (clamp(LR^), nll)   (HCFlowNet_SR_arch.py:47-67). ``noise``: optional injected U[0,1)
+        tensor replacing the internal torch.rand draw (:52)."""
+        self._check_inference()
+        dev = next(self.parameters()).device
+        eng, idx = self._engine_for(dev)
+        hr = self._prep(hr, dev)
+        B, c, H, W = hr.shape
+        s = self.cfg.scale
+        assert H % s == 0 and W % s == 0, "{}".format((H, W, 2))
+        if noise is None:
+            noise = torch.rand(hr.shape, device=dev)
+        noise = self._prep(noise, dev)
+        lr_t = None if lr is None else self._prep(lr, dev)
+        out_lr = torch.empty(B, 3, H // s, W // s, device=dev)
+        nll = torch.empty(1, device=dev)
+        logdet = torch.empty(B, device=dev)
+        zraw = torch.empty(B, 3, H // s, W // s, device=dev) if return_internals else None
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_forward_sr(eng.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(),
+                                        noise.data_ptr(), out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(),
+                                        None if zraw is None else zraw.data_ptr(), B, H, W, self._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_forward_sr")
+        if return_internals:
+            return out_lr, nll[0], logdet, zraw
+        return out_lr, nll[0]
+
+    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):
+        """lr (+ sampled z) -> clamp(HR)   (HCFlowNet_SR_arch.py:70-75)."""
+        return self._inverse(lr, eps_std, eps=eps, clamp=clamp)
+
+
+class HCFlowNet_Rescaling(_EngineModule):
+    """Drop-in for models.modules.HCFlowNet_Rescaling_arch.HCFlowNet_Rescaling (:13-54)."""
+
+    def __init__(self, opt, step=None):
+        super(HCFlowNet_Rescaling, self).__init__()
+        self.quant = opt_get(opt, ['datasets', 'train', 'quant'], 256)
+        self._setup(opt)
+        assert not self.cfg.sr
+
+    def forward(self, hr=None, lr=None, z=None, u=None, eps_std=None,
+                add_gt_noise=False, step=None, reverse=False, training=True, eps=None):
+        if not reverse:
+            return self.normal_flow_diracLR(hr, lr, u, step=step, training=training)
+        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps)
+
+    def normal_flow_diracLR(self, hr, lr=None, u=None, step=None, training=True, clamp=True):
+        """hr -> (clamp(LR^), z1, z2)   (HCFlowNet_Rescaling_arch.py:39-46)."""
+        self._check_inference()
+        dev = next(self.parameters()).device
+        eng, idx = self._engine_for(dev)
+        hr = self._prep(hr, dev)
+        B, c, H, W = hr.shape
+        assert H % 4 == 0 and W % 4 == 0, "{}".format((H, W, 2))
+        cfg = self.cfg
+        out_lr = torch.empty(B, 3, H // 4, W // 4, device=dev)
+        c0 = cfg.level_channels(0) - cfg.split_channels(0)
+        c1 = cfg.level_channels(1) - cfg.split_channels(1)
+        z1 = torch.empty(B, c0, H // 2, W // 2, device=dev)
+        z2 = torch.empty(B, c1, H // 4, W // 4, device=dev)
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_forward_rescale(eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(),
+                                             B, H, W, 0 if clamp else _lib.FLAG_NO_CLAMP, self._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_forward_rescale")
+        return out_lr, z1, z2
+
+    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):
+        """lr (+ sampled z) -> clamp(HR)   (HCFlowNet_Rescaling_arch.py:49-54)."""
+        return self._inverse(lr, eps_std, eps=eps, clamp=clamp)
+
+    def get_score(self, disc_loss_sigma, z):
+        """HCFlowNet_Rescaling.get_score (:57-60), unused by every config; kept for API parity."""
+        score_real = 0.5 * (1 - 1 / (disc_loss_sigma ** 2)) * (z ** 2).sum(dim=[1, 2, 3]) - \
+            z.shape[1] * z.shape[2] * z.shape[3] * math.log(disc_loss_sigma)
+        return -score_real

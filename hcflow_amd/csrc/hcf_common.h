@@ -1,0 +1,120 @@
+// Shared declarations for the HCFlow MI355X engine (gfx950 only).
+//
+// Data layout: every activation lives in HBM as dense NHWC fp32, [B][H][W][cs] with channel
+// stride cs = roundup4(C) so that a pixel's channel vector is 16-byte aligned and float4-loadable.
+// A `View` names a channel window [c0, c0+n) of such a tensor, optionally read through a nearest
+// upsample by 2^up (the reference's F.interpolate(mode='nearest'), FlowNet_SR_x4.py:98,117, is
+// folded into the consumer's addressing and never materialised).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HCF_OK 0
+#define HCF_ERR_ARG (-1)
+#define HCF_ERR_HIP (-2)
+#define HCF_ERR_STATE (-3)
+#define HCF_ERR_KEY (-4)
+#define HCF_ERR_SHAPE (-5)
+#define HCF_ERR_UNSUPPORTED (-6)
+#define HCF_ERR_NOMEM (-7)
+
+namespace hcf {
+
+struct View {
+  float* p;   // base of the NHWC tensor
+  int cs;     // channel stride (floats per pixel)
+  int c0;     // first channel of the window
+  int n;      // channels in the window
+  int up;     // log2 nearest-upsample factor when read as a conv source (0 = none)
+};
+
+static inline View mkview(float* p, int cs, int c0, int n, int up = 0) {
+  View v; v.p = p; v.cs = cs; v.c0 = c0; v.n = n; v.up = up; return v;
+}
+
+constexpr int kMaxSrc = 3;
+
+// ---- fused conv (3x3 pad 1, or 1x1) ---------------------------------------------------------
+// out[pix][oc] = res2 + rs2 * ( res1 + rs1 * act( (sum_k A[pix,k] W[k,oc] + bias[oc]) * scale[oc] ) )
+// (terms with a null residual are skipped). Covers nn.Conv2d+bias(+LeakyReLU), Basic.Conv2d
+// (+ActNorm+ReLU), Conv2dZeros (*exp(3 logs)), RDB "x5*0.2+x" and RRDB "out*0.2+x" epilogues.
+struct ConvArgs {
+  View src[kMaxSrc];
+  int nsrc;
+  int B, H, W;             // output resolution (sources with up>0 are read at H>>up, W>>up)
+  const float* wpack;      // [nchunk][taps][2][npad][8]  (see pack_conv_weights)
+  int nchunk;              // ceil(Kvirtual / 16)
+  const float* bias;       // [npad]
+  const float* scale;      // [npad]
+  int act;                 // 0 none, 1 relu, 2 leaky relu 0.2
+  View out;                // n = cout
+  View res1; float rs1;    // res1.p == nullptr -> skipped
+  View res2; float rs2;
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+
+int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
+
+// ---- flow-step glue --------------------------------------------------------------------------
+enum { CPL_AFFINE = 0, CPL_SHIFT3 = 1 };
+
+struct StepArgs {
+  int B, H, W;
+  int C;                 // channels of z
+  int ns;                // CPL_AFFINE: channels [ns, C) are transformed, h = (shift, scale) interleaved
+                         // CPL_SHIFT3: channels [0, 3) are shifted by h[0:3], ns unused
+  int mode;
+  View z;                // input
+  View h;                // coupling-network output
+  View out;              // output
+  const float* mat;      // C x C row-major (W^-1 for inverse, W for forward) or nullptr (no permutation)
+  const float* an_bias;  // [C]
+  const float* an_mul;   // [C]  exp(-logs) (inverse) or exp(logs) (forward)
+  float* partial;        // forward couple: per-block partial sums of logscale, [B][nblk]; else nullptr
+  int partial_stride;    // floats between consecutive samples in `partial`
+};
+
+int launch_step_tail_inv(const StepArgs& a, hipStream_t st);     // coupling^-1, W^-1, actnorm^-1
+int launch_step_head_fwd(const StepArgs& a, hipStream_t st);     // actnorm, W           (h unused)
+int launch_step_couple_fwd(const StepArgs& a, hipStream_t st);   // coupling (in place capable) + sum logscale
+int step_blocks_per_sample(int H, int W);
+int step_cmax(int C);   // register-array bucket (8/12/24/48) used by the step kernels; -1 if C > 48
+
+// ---- Gaussian prior / misc elementwise -------------------------------------------------------
+struct GaussArgs {
+  int B, H, W, C;        // C = channels of the latent (h has 2C: mean = h[0::2], s = h[1::2])
+  View h;
+  int rescale;           // 0: logs = s (SR, ConditionalFlow.py:54,62); 1: logs = 0.318 atan(2 s) (:78,90)
+  // sample
+  const float* eps;      // NCHW [B,C,H,W] already N(0,tau) (injected), or nullptr -> device Philox
+  float tau; uint64_t seed; uint64_t offset;
+  View out;              // sample: latent out.  logp/encode: latent in
+  float* aux;            // encode (rescale fwd): NCHW output z = (a-mean) exp(-logs)
+  float* partial; int partial_stride;
+};
+int launch_gauss_sample(const GaussArgs& a, hipStream_t st);
+int launch_gauss_logp(const GaussArgs& a, hipStream_t st);      // SR forward: partial sums of log p
+int launch_gauss_encode(const GaussArgs& a, hipStream_t st);    // rescaling forward
+
+int launch_nchw_to_nhwc(const float* src, View dst, int B, int C, int H, int W, hipStream_t st);
+int launch_nhwc_to_nchw(View src, float* dst, int B, int C, int H, int W, int clamp01, hipStream_t st);
+// squeeze2d / unsqueeze2d, factor 2, channel order c*4 + i*2 + j (Basic.py:127-157)
+int launch_squeeze(View in, View out, int B, int C, int H, int W, hipStream_t st);     // in: [H,W,C] -> out [H/2,W/2,4C]
+int launch_unsqueeze(View in, View out, int B, int C4, int H, int W, hipStream_t st);  // in: [H,W,C4] -> out [2H,2W,C4/4]
+// fused boundary forms
+int launch_nchw_squeeze(const float* src, const float* noise, float quant, View out, int B, int C, int H, int W,
+                        int haar, hipStream_t st);   // (src + noise/quant) -> squeeze/haar -> NHWC
+int launch_unsqueeze_nchw(View in, float* dst, int B, int C4, int H, int W, int haar, int clamp01, hipStream_t st);
+int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t st);
+int launch_haar_inv(View in, View out, int B, int C4, int H, int W, hipStream_t st);
+int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st);
+// SR forward tail: zq = round(clamp(z,0,1)*255)/255 ; lr_hat NCHW = zq ; partial += logp(lr; mean zq, logs -6)
+int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W,
+                      float* partial, int partial_stride, hipStream_t st);
+// out[b] = cst + sum_j partial[b*stride + j], j < n  (double accumulation); optional nll = mean(-out)/(ln2*pixels)
+int launch_reduce_partials(const float* partial, int stride, int n, int B, double cst, double pixels,
+                           float* out_logdet, float* out_nll, hipStream_t st);
+int launch_fill(float* p, size_t n, float v, hipStream_t st);
+
+}  // namespace hcf

@@ -1,0 +1,975 @@
+// Engine: builds the HCFlow layer graph from hcf_config, packs parameters for the kernels,
+// owns the activation arena and enqueues the forward / inverse pass on the caller's stream.
+//
+// Reference structure mirrored here (state_dict names must match for strict checkpoint loads):
+//   FlowNet.__init__            FlowNet_SR_x4.py:11-72, FlowNet_SR_x8.py:11-79, FlowNet_Rescaling_x4.py:11-80
+//   FlowStep                    FlowStep.py:8-64
+//   ConditionalFlow             ConditionalFlow.py:15-110
+//   FCN / DenseBlock / RRDB     Basic.py:329-447
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hcflow.h"
+#include "hcf_common.h"
+
+namespace hcf {
+int step_cmax(int C);
+
+static inline int ru4(int c) { return (c + 3) & ~3; }
+
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+};
+
+struct Spec {
+  std::string key;
+  std::vector<int64_t> shape;
+};
+
+// One fused conv layer, packed for conv_mfma_kernel
+struct Conv {
+  int taps = 9, cout = 0, nsrc = 0, src_n[kMaxSrc] = {0, 0, 0}, nchunk = 0, npad = 0, act = ACT_NONE;
+  float *wpack = nullptr, *bias = nullptr, *scale = nullptr;   // device
+  double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
+};
+
+struct Step {
+  int C = 0, ns = 0, mode = CPL_AFFINE, cond = 0, cmax = 0;
+  bool lr_vs_others = true, has_mat = false, fcn = true;
+  int f_in = 0, f_out = 0, hid = 0;
+  Conv c[5];                        // FCN: c[0..2]; DenseBlock: c[0..4]
+  float *mat_inv = nullptr, *mat_fwd = nullptr, *bias = nullptr, *mul_inv = nullptr, *mul_fwd = nullptr;
+  double ld_const = 0;              // per pixel: sum(actnorm logs) + slogdet(W)
+};
+
+struct Rdb { Conv c[5]; };
+struct Rrdb { Rdb r[3]; };
+
+struct CondFlow {
+  int level = 0, C = 0, ns = 0, Ca = 0, nlc = 0;
+  Conv conv_first, trunk_conv1, head;
+  std::vector<Rrdb> trunk0, trunk1;
+  std::vector<Step> steps;
+};
+
+struct Level {
+  int C = 0, ns = 0;
+  std::vector<Step> steps;
+  CondFlow cf;
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, top = 0, peak = 0;
+  bool dry = false;
+  float* alloc(size_t nfloat) {
+    size_t bytes = (nfloat * sizeof(float) + 64 + 255) & ~(size_t)255;   // +64: 4-float over-read slack
+    float* p = dry ? reinterpret_cast<float*>((uintptr_t)0x1000 + top) : reinterpret_cast<float*>(base + top);
+    top += bytes;
+    if (top > peak) peak = top;
+    return p;
+  }
+};
+
+// w: PyTorch [cout][cin][k][k]. Virtual K order = sources concatenated, each padded to a multiple
+// of 4 channels; packed as [chunk][tap][kg(2)][npad][8] plus one zero K-step so the kernel's
+// one-step-ahead weight prefetch never reads past the end.
+void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc, std::vector<float>& pk,
+                       int& nchunk, int& npad) {
+  int kv = 0;
+  for (int i = 0; i < nsrc; ++i) kv += ru4(srcs[i]);
+  nchunk = (kv + 15) / 16;
+  npad = ((cout + 31) / 32) * 32;
+  std::vector<int> vmap((size_t)nchunk * 16, -1);     // virtual channel -> real input channel (or -1)
+  int v = 0, real = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    for (int c = 0; c < srcs[i]; ++c) vmap[v + c] = real + c;
+    v += ru4(srcs[i]);
+    real += srcs[i];
+  }
+  const size_t step = (size_t)npad * 8;
+  pk.assign(((size_t)nchunk * taps * 2 + 1) * step, 0.f);
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int t = 0; t < taps; ++t)
+      for (int kg = 0; kg < 2; ++kg)
+        for (int n = 0; n < cout; ++n)
+          for (int e = 0; e < 8; ++e) {
+            const int ci = vmap[ch * 16 + kg * 8 + e];
+            if (ci < 0) continue;
+            pk[(((size_t)ch * taps + t) * 2 + kg) * step + (size_t)n * 8 + e] = w[((size_t)n * cin + ci) * taps + t];
+          }
+}
+
+}  // namespace hcf
+
+using namespace hcf;
+
+struct hcf_engine {
+  hcf_config cfg;
+  std::vector<Spec> specs;
+  std::map<std::string, HostTensor> params;
+  std::vector<Level> levels;
+  std::vector<float*> dev_allocs;      // packed weights
+  size_t weight_bytes = 0;
+  bool finalized = false;
+  int device = -1;
+  Arena arena;
+  std::string err;
+  // conv profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_flops = 0;
+  // build state
+  bool spec_mode = true;
+  int rc = HCF_OK;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    if (rc == HCF_OK) rc = code;
+    return code;
+  }
+
+  // ---------------------------------------------------------------- config helpers
+  int level_channels(int level) const {
+    int c = cfg.in_nc;
+    for (int l = 0; l <= level; ++l) {
+      c *= 4;
+      if (l < level) c = (l < cfg.L - 1) ? c / 2 : 3;
+    }
+    return c;
+  }
+  int split_channels(int level) const { return level < cfg.L - 1 ? level_channels(level) / 2 : 3; }
+  int cond_ch() const { return cfg.rrdb_nf * (cfg.kind == HCF_KIND_SR ? 2 : 1); }
+  bool sr() const { return cfg.kind == HCF_KIND_SR; }
+
+  // ---------------------------------------------------------------- parameter access
+  const float* P(const std::string& key, std::vector<int64_t> shape) {
+    if (spec_mode) {
+      specs.push_back({key, shape});
+      return nullptr;
+    }
+    auto it = params.find(key);
+    if (it == params.end() || !it->second.set) {
+      fail(HCF_ERR_KEY, "missing parameter: " + key);
+      return nullptr;
+    }
+    if (it->second.shape != shape) {
+      fail(HCF_ERR_SHAPE, "shape mismatch for parameter: " + key);
+      return nullptr;
+    }
+    return it->second.data.data();
+  }
+
+  float* upload(const std::vector<float>& v) {
+    float* d = nullptr;
+    if (hipMalloc(&d, v.size() * sizeof(float)) != hipSuccess) {
+      fail(HCF_ERR_NOMEM, "hipMalloc failed for packed weights");
+      return nullptr;
+    }
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      fail(HCF_ERR_HIP, "hipMemcpy H2D failed");
+      hipFree(d);
+      return nullptr;
+    }
+    dev_allocs.push_back(d);
+    weight_bytes += v.size() * sizeof(float);
+    return d;
+  }
+
+  // ---------------------------------------------------------------- conv packing
+  void pack_conv(Conv& cv, const float* w, const float* bias, const float* scale, int cin, int cout, int k,
+                 std::vector<int> srcs, int act) {
+    cv.taps = k * k;
+    cv.cout = cout;
+    cv.act = act;
+    cv.nsrc = (int)srcs.size();
+    int kv = 0, csum = 0;
+    for (int i = 0; i < cv.nsrc; ++i) {
+      cv.src_n[i] = srcs[i];
+      kv += ru4(srcs[i]);
+      csum += srcs[i];
+    }
+    cv.nchunk = (kv + 15) / 16;
+    cv.npad = ((cout + 31) / 32) * 32;
+    cv.flops_per_pixel = 2.0 * cv.taps * cin * cout;
+    if (spec_mode) return;
+    if (csum != cin) {
+      fail(HCF_ERR_SHAPE, "internal: conv source channels do not add up");
+      return;
+    }
+    if (!w) return;
+    std::vector<float> pk;
+    pack_conv_weights(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk, cv.nchunk, cv.npad);
+    std::vector<float> b(cv.npad, 0.f), s(cv.npad, 1.f);
+    for (int n = 0; n < cout; ++n) {
+      if (bias) b[n] = bias[n];
+      if (scale) s[n] = scale[n];
+    }
+    cv.wpack = upload(pk);
+    cv.bias = upload(b);
+    cv.scale = upload(s);
+  }
+
+  // nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+  void build_conv(Conv& cv, const std::string& p, int cin, int cout, std::vector<int> srcs, int act) {
+    const float* w = P(p + ".weight", {cout, cin, 3, 3});
+    const float* b = P(p + ".bias", {cout});
+    pack_conv(cv, w, b, nullptr, cin, cout, 3, srcs, act);
+  }
+  // Basic.Conv2d with ActNorm (Basic.py:14-53) + ReLU
+  void build_conv_an(Conv& cv, const std::string& p, int cin, int cout, int k, std::vector<int> srcs) {
+    const float* w = P(p + ".weight", {cout, cin, k, k});
+    const float* ab = P(p + ".actnorm.bias", {1, cout, 1, 1});
+    const float* al = P(p + ".actnorm.logs", {1, cout, 1, 1});
+    std::vector<float> sc(cout, 1.f);
+    if (al)
+      for (int i = 0; i < cout; ++i) sc[i] = expf(al[i]);
+    pack_conv(cv, w, ab, al ? sc.data() : nullptr, cin, cout, k, srcs, ACT_RELU);
+  }
+  // Basic.Conv2dZeros (Basic.py:57-72): (conv + bias) * exp(logs * 3)
+  void build_conv_zeros(Conv& cv, const std::string& p, int cin, int cout, std::vector<int> srcs) {
+    const float* w = P(p + ".weight", {cout, cin, 3, 3});
+    const float* b = P(p + ".bias", {cout});
+    const float* lg = P(p + ".logs", {cout, 1, 1});
+    std::vector<float> sc(cout, 1.f);
+    if (lg)
+      for (int i = 0; i < cout; ++i) sc[i] = expf(lg[i] * 3.f);
+    pack_conv(cv, w, b, lg ? sc.data() : nullptr, cin, cout, 3, srcs, ACT_NONE);
+  }
+
+  static std::vector<int> srcs2(int a, int b) {
+    std::vector<int> v;
+    v.push_back(a);
+    if (b > 0) v.push_back(b);
+    return v;
+  }
+
+  // ---------------------------------------------------------------- linear algebra (host, fp64)
+  static bool invert(const std::vector<double>& A, int n, std::vector<double>& inv, double& logabsdet) {
+    std::vector<double> a(A);
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+    logabsdet = 0.0;
+    for (int col = 0; col < n; ++col) {
+      int piv = col;
+      double best = fabs(a[(size_t)col * n + col]);
+      for (int r = col + 1; r < n; ++r)
+        if (fabs(a[(size_t)r * n + col]) > best) { best = fabs(a[(size_t)r * n + col]); piv = r; }
+      if (best == 0.0) return false;
+      if (piv != col)
+        for (int c = 0; c < n; ++c) {
+          std::swap(a[(size_t)piv * n + c], a[(size_t)col * n + c]);
+          std::swap(inv[(size_t)piv * n + c], inv[(size_t)col * n + c]);
+        }
+      const double d = a[(size_t)col * n + col];
+      logabsdet += log(fabs(d));
+      for (int c = 0; c < n; ++c) { a[(size_t)col * n + c] /= d; inv[(size_t)col * n + c] /= d; }
+      for (int r = 0; r < n; ++r) {
+        if (r == col) continue;
+        const double f = a[(size_t)r * n + col];
+        if (f == 0.0) continue;
+        for (int c = 0; c < n; ++c) {
+          a[(size_t)r * n + c] -= f * a[(size_t)col * n + c];
+          inv[(size_t)r * n + c] -= f * inv[(size_t)col * n + c];
+        }
+      }
+    }
+    return true;
+  }
+
+  // ---------------------------------------------------------------- FlowStep
+  void build_step(Step& s, const std::string& p, int C, int cond, int perm, int coupling, int nn_module, int hid,
+                  bool lr_vs_others) {
+    s.C = C;
+    s.cond = cond;
+    s.cmax = step_cmax(C);
+    s.lr_vs_others = lr_vs_others;
+    s.hid = hid;
+    s.fcn = (nn_module == HCF_NN_FCN);
+    if (s.cmax < 0) { fail(HCF_ERR_UNSUPPORTED, "flow step with more than 48 channels"); return; }
+    const float* ab = P(p + ".actnorm.bias", {1, C, 1, 1});
+    const float* al = P(p + ".actnorm.logs", {1, C, 1, 1});
+    const float* W = nullptr;
+    s.has_mat = (perm == HCF_PERM_INVCONV);
+    if (s.has_mat) W = P(p + ".permute.weight", {C, C});
+    // coupling geometry (AffineCouplings.py:18-19, 101-106)
+    int z1_n;
+    if (coupling == HCF_COUPLING_AFFINE) {
+      s.mode = CPL_AFFINE; s.ns = C / 2; z1_n = C / 2; s.f_out = (C - C / 2) * 2;
+    } else if (lr_vs_others) {
+      s.mode = CPL_AFFINE; s.ns = 3; z1_n = 3; s.f_out = (C - 3) * 2;
+    } else {
+      s.mode = CPL_SHIFT3; s.ns = 3; z1_n = C - 3; s.f_out = 3;
+    }
+    s.f_in = z1_n + cond;
+    const std::string f = p + ".affine.f";
+    if (s.fcn) {
+      build_conv_an(s.c[0], f + ".conv1", s.f_in, hid, 3, srcs2(z1_n, cond));
+      build_conv_an(s.c[1], f + ".conv2", hid, hid, 1, srcs2(hid, 0));
+      build_conv_zeros(s.c[2], f + ".conv3", hid, s.f_out, srcs2(hid, 0));
+    } else {
+      // DenseBlock(in, out, gc=hid) (Basic.py:329-356); dense concat order is (x, x1, x2, ...) and x itself
+      // is cat(z1, u) when conditional -> sources: z1 [, u], growth
+      for (int i = 0; i < 5; ++i) {
+        std::vector<int> srcs;
+        srcs.push_back(z1_n);
+        if (cond > 0) srcs.push_back(cond);
+        if (i > 0) srcs.push_back(i * hid);
+        if ((int)srcs.size() > kMaxSrc) { fail(HCF_ERR_UNSUPPORTED, "too many conv sources"); return; }
+        build_conv(s.c[i], f + ".conv" + std::to_string(i + 1), s.f_in + i * hid, i < 4 ? hid : s.f_out, srcs,
+                   i < 4 ? ACT_LRELU : ACT_NONE);
+      }
+    }
+    if (spec_mode || rc != HCF_OK) return;
+    const int M = s.cmax;
+    std::vector<float> bias(M, 0.f), mi(M, 0.f), mf(M, 0.f);
+    double sumlogs = 0;
+    for (int c = 0; c < C; ++c) {
+      bias[c] = ab[c];
+      mi[c] = expf(-al[c]);
+      mf[c] = expf(al[c]);
+      sumlogs += (double)al[c];
+    }
+    s.bias = upload(bias);
+    s.mul_inv = upload(mi);
+    s.mul_fwd = upload(mf);
+    s.ld_const = sumlogs;
+    if (s.has_mat) {
+      std::vector<double> A((size_t)C * C), inv;
+      for (int i = 0; i < C * C; ++i) A[i] = (double)W[i];
+      double lad = 0;
+      if (!invert(A, C, inv, lad)) { fail(HCF_ERR_ARG, "singular invertible-conv weight: " + p); return; }
+      std::vector<float> wi((size_t)M * M, 0.f), wf((size_t)M * M, 0.f);
+      for (int r = 0; r < C; ++r)
+        for (int c = 0; c < C; ++c) {
+          wi[(size_t)r * M + c] = (float)inv[(size_t)r * C + c];    // inverse(W.double()).float(), Permutations.py:74
+          wf[(size_t)r * M + c] = W[(size_t)r * C + c];
+        }
+      s.mat_inv = upload(wi);
+      s.mat_fwd = upload(wf);
+      s.ld_const += lad;
+    }
+  }
+
+  void build_rdb(Rdb& r, const std::string& p, int nf, int gc) {
+    for (int i = 0; i < 4; ++i)
+      build_conv(r.c[i], p + ".conv" + std::to_string(i + 1), nf + i * gc, gc, srcs2(nf, i * gc), ACT_LRELU);
+    build_conv(r.c[4], p + ".conv5", nf + 4 * gc, nf, srcs2(nf, 4 * gc), ACT_NONE);
+  }
+
+  void build_condflow(CondFlow& cf, const std::string& p, int level) {
+    cf.level = level;
+    cf.C = level_channels(level);
+    cf.ns = split_channels(level);
+    cf.Ca = cf.C - cf.ns;
+    cf.nlc = cfg.L - 1 - level;
+    const int nf = cfg.rrdb_nf, gc = cfg.rrdb_gc, cc = cond_ch();
+    std::vector<int> srcs;
+    srcs.push_back(cf.ns);
+    for (int i = 0; i < cf.nlc; ++i) srcs.push_back(cc);
+    build_conv(cf.conv_first, p + ".conv_first", cf.ns + cc * cf.nlc, nf, srcs, ACT_NONE);
+    cf.trunk0.resize(cfg.rrdb_nb[0]);
+    for (int n = 0; n < cfg.rrdb_nb[0]; ++n)
+      for (int r = 0; r < 3; ++r)
+        build_rdb(cf.trunk0[n].r[r], p + ".RRDB_trunk0." + std::to_string(n) + ".RDB" + std::to_string(r + 1), nf, gc);
+    cf.trunk1.resize(cfg.rrdb_nb[1]);
+    for (int n = 0; n < cfg.rrdb_nb[1]; ++n)
+      for (int r = 0; r < 3; ++r)
+        build_rdb(cf.trunk1[n].r[r], p + ".RRDB_trunk1." + std::to_string(n) + ".RDB" + std::to_string(r + 1), nf, gc);
+    build_conv(cf.trunk_conv1, p + ".trunk_conv1", nf, nf, srcs2(nf, 0), ACT_NONE);
+    cf.steps.resize(cfg.after[level]);
+    for (int k = 0; k < cfg.after[level]; ++k)
+      build_step(cf.steps[k], p + ".additional_flow_steps." + std::to_string(k), cf.Ca, cc, cfg.c_perm, cfg.c_coupling,
+                 cfg.c_nn_module, cfg.c_hidden, true);
+    build_conv_zeros(cf.head, p + ".f", cc, cf.Ca * 2, srcs2(cc, 0));
+  }
+
+  // Walk the module tree in the reference's registration order. spec_mode: record keys only.
+  int build() {
+    levels.clear();
+    levels.resize(cfg.L);
+    int idx = 0;
+    int C = cfg.in_nc;
+    for (int level = 0; level < cfg.L; ++level) {
+      Level& lv = levels[level];
+      if (cfg.squeeze == HCF_SQUEEZE_HAAR) {
+        const float* hw = P("flow.layers." + std::to_string(idx) + ".haar_weights", {4 * C, 1, 2, 2});
+        if (hw) {
+          // frozen +-1 pattern (Basic.py:455-468); anything else is not a Haar transform
+          for (int c = 0; c < 4 * C; ++c)
+            for (int i = 0; i < 2; ++i)
+              for (int j = 0; j < 2; ++j) {
+                const int k = c % 4;
+                const bool neg = (k == 1 && j == 1) || (k == 2 && i == 1) || (k == 3 && (i != j));
+                if (hw[(c * 2 + i) * 2 + j] != (neg ? -1.f : 1.f))
+                  return fail(HCF_ERR_UNSUPPORTED, "haar_weights differ from the fixed Haar pattern");
+              }
+        }
+      }
+      idx++;
+      C *= 4;
+      lv.C = C;
+      const int nmain = cfg.K[level] - cfg.after[level];
+      lv.steps.resize(nmain);
+      for (int k = 0; k < nmain; ++k) {
+        const bool lrv = sr() ? true : (k % 2 == 0);
+        build_step(lv.steps[k], "flow.layers." + std::to_string(idx), C, 0, cfg.perm, cfg.coupling, cfg.nn_module,
+                   cfg.hidden, lrv);
+        idx++;
+      }
+      lv.ns = split_channels(level);
+      idx++;   // Split
+      C = lv.ns;
+    }
+    for (int level = 0; level < cfg.L; ++level)
+      build_condflow(levels[level].cf, "flow.level" + std::to_string(level) + "_condFlow", level);
+    return rc;
+  }
+
+  void free_weights() {
+    for (float* p : dev_allocs) hipFree(p);
+    dev_allocs.clear();
+    weight_bytes = 0;
+  }
+
+  // ---------------------------------------------------------------- execution helpers
+  hipStream_t st = nullptr;
+  bool dry() const { return arena.dry; }
+
+  struct Buf {
+    float* p; int C; int cs;
+    View v(int c0, int n, int up = 0) const { return mkview(p, cs, c0, n, up); }
+    View all() const { return mkview(p, cs, 0, C, 0); }
+  };
+  Buf alloc(int B, int H, int W, int C) {
+    Buf b;
+    b.C = C;
+    b.cs = ru4(C);
+    b.p = arena.alloc((size_t)B * H * W * b.cs);
+    return b;
+  }
+
+  int B_ = 0;   // batch of the running pass
+
+  void run_conv(const Conv& cv, std::vector<View> srcs, int H, int W, View out, View res1 = mkview(nullptr, 0, 0, 0),
+                float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f) {
+    if (rc != HCF_OK) return;
+    if ((int)srcs.size() != cv.nsrc) { fail(HCF_ERR_STATE, "internal: conv source count"); return; }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < cv.nsrc; ++i) {
+      a.src[i] = srcs[i];
+      if (srcs[i].n != cv.src_n[i]) { fail(HCF_ERR_STATE, "internal: conv source width"); return; }
+    }
+    for (int i = cv.nsrc; i < kMaxSrc; ++i) a.src[i] = srcs[0];
+    a.nsrc = cv.nsrc;
+    a.B = B_; a.H = H; a.W = W;
+    a.wpack = cv.wpack; a.nchunk = cv.nchunk; a.bias = cv.bias; a.scale = cv.scale; a.act = cv.act;
+    a.out = out; a.out.n = cv.cout;
+    a.res1 = res1; a.rs1 = rs1; a.res2 = res2; a.rs2 = rs2;
+    if (dry()) return;
+    if (prof) {
+      if (prof_used == prof_events.size()) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        prof_events.push_back({e0, e1});
+      }
+      hipEventRecord(prof_events[prof_used].first, st);
+    }
+    const int r = launch_conv(a, cv.taps, st);
+    if (prof) {
+      hipEventRecord(prof_events[prof_used].second, st);
+      prof_used++;
+      prof_flops += cv.flops_per_pixel * (double)B_ * H * W;
+    }
+    if (r != HCF_OK) fail(r, "conv launch failed");
+  }
+
+#define HCF_LAUNCH(expr)                                    \
+  do {                                                      \
+    if (rc == HCF_OK && !dry()) {                           \
+      const int r_ = (expr);                                \
+      if (r_ != HCF_OK) fail(r_, "launch failed: " #expr);  \
+    }                                                       \
+  } while (0)
+
+  struct Scratch {      // per-level temporaries
+    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow;
+  };
+
+  // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
+  void run_coupling_net(const Step& s, View z1, const View* u, int H, int W, Scratch& sc) {
+    std::vector<View> in;
+    in.push_back(z1);
+    if (s.cond > 0) {
+      if (!u) { fail(HCF_ERR_UNSUPPORTED, "conditional coupling without a condition tensor"); return; }
+      in.push_back(*u);
+    }
+    if (s.fcn) {
+      run_conv(s.c[0], in, H, W, sc.h1.v(0, s.hid));
+      run_conv(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
+      run_conv(s.c[2], {sc.h2.v(0, s.hid)}, H, W, sc.hout.v(0, s.f_out));
+    } else {
+      for (int i = 0; i < 5; ++i) {
+        std::vector<View> srcs = in;
+        if (i > 0) srcs.push_back(sc.grow.v(0, i * s.hid));
+        if (i < 4) run_conv(s.c[i], srcs, H, W, sc.grow.v(i * s.hid, s.hid));
+        else run_conv(s.c[i], srcs, H, W, sc.hout.v(0, s.f_out));
+      }
+    }
+  }
+
+  View step_z1(const Step& s, const Buf& z) const {
+    if (s.mode == CPL_AFFINE) return z.v(0, s.ns);
+    return z.v(3, s.C - 3);
+  }
+
+  // FlowStep.reverse_flow (FlowStep.py:53-64), in place on z
+  void run_step_inverse(const Step& s, const Buf& z, const View* u, int H, int W, Scratch& sc) {
+    run_coupling_net(s, step_z1(s, z), u, H, W, sc);
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B_; a.H = H; a.W = W; a.C = s.C; a.ns = s.ns; a.mode = s.mode;
+    a.z = z.all(); a.h = sc.hout.v(0, s.f_out); a.out = z.all();
+    a.mat = s.has_mat ? s.mat_inv : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_inv;
+    HCF_LAUNCH(launch_step_tail_inv(a, st));
+  }
+
+  // FlowStep.normal_flow (FlowStep.py:40-51), in place on z; partial slot advanced when `partial`
+  void run_step_forward(const Step& s, const Buf& z, const View* u, int H, int W, Scratch& sc, float* partial,
+                        int pstride, int& pslot) {
+    StepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B_; a.H = H; a.W = W; a.C = s.C; a.ns = s.ns; a.mode = s.mode;
+    a.z = z.all(); a.out = z.all();
+    a.mat = s.has_mat ? s.mat_fwd : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_fwd;
+    HCF_LAUNCH(launch_step_head_fwd(a, st));
+    run_coupling_net(s, step_z1(s, z), u, H, W, sc);
+    a.h = sc.hout.v(0, s.f_out);
+    a.mat = nullptr;
+    if (partial && s.mode == CPL_AFFINE) {
+      a.partial = partial + pslot;
+      a.partial_stride = pstride;
+      pslot += step_blocks_per_sample(H, W);
+    }
+    HCF_LAUNCH(launch_step_couple_fwd(a, st));
+  }
+
+  // ResidualDenseBlock (Basic.py:379-385) with optional second residual (RRDB tail, :394-398)
+  void run_rdb(const Rdb& r, View xin, const Buf& grow, int H, int W, View out, View res2, float rs2) {
+    const int gc = cfg.rrdb_gc;
+    for (int i = 0; i < 4; ++i) {
+      std::vector<View> srcs;
+      srcs.push_back(xin);
+      if (i > 0) srcs.push_back(grow.v(0, i * gc));
+      run_conv(r.c[i], srcs, H, W, grow.v(i * gc, gc));
+    }
+    run_conv(r.c[4], {xin, grow.v(0, 4 * gc)}, H, W, out, xin, 0.2f, res2, rs2);
+  }
+
+  void run_rrdb(const Rrdb& rr, View x0, View out, int H, int W, Scratch& sc) {
+    const int nf = cfg.rrdb_nf;
+    const View none = mkview(nullptr, 0, 0, 0);
+    run_rdb(rr.r[0], x0, sc.rgrow, H, W, sc.t1.v(0, nf), none, 0.f);
+    run_rdb(rr.r[1], sc.t1.v(0, nf), sc.rgrow, H, W, sc.t2.v(0, nf), none, 0.f);
+    run_rdb(rr.r[2], sc.t2.v(0, nf), sc.rgrow, H, W, out, x0, 0.2f);
+  }
+
+  // ConditionalFlow.get_conditional_feature_SR / _Rescaling (ConditionalFlow.py:99-110) -> cfbuf
+  void run_cond_features(const CondFlow& cf, std::vector<View> u, int H, int W, const Buf& cfbuf, Scratch& sc) {
+    const int nf = cfg.rrdb_nf;
+    run_conv(cf.conv_first, u, H, W, sc.f0.v(0, nf));
+    View cur = sc.f0.v(0, nf);
+    const View f1 = sr() ? cfbuf.v(0, nf) : sc.x.v(0, nf);
+    for (size_t n = 0; n < cf.trunk0.size(); ++n) {
+      run_rrdb(cf.trunk0[n], cur, f1, H, W, sc);
+      cur = f1;
+    }
+    if (sr() && cf.trunk0.empty()) {
+      HCF_LAUNCH(launch_copy_view(cur, f1, B_, H, W, st));
+      cur = f1;
+    }
+    const View x = sc.x.v(0, nf);
+    for (size_t n = 0; n < cf.trunk1.size(); ++n) {
+      run_rrdb(cf.trunk1[n], cur, x, H, W, sc);
+      cur = x;
+    }
+    const View f2 = sr() ? cfbuf.v(nf, nf) : cfbuf.v(0, nf);
+    run_conv(cf.trunk_conv1, {cur}, H, W, f2, sc.f0.v(0, nf), 1.0f);
+  }
+
+  Scratch alloc_scratch(int H, int W) {
+    Scratch sc;
+    int hid = std::max(cfg.hidden, cfg.c_hidden);
+    int fo = 4;
+    for (const Level& lv : levels) {
+      for (const Step& s : lv.steps) fo = std::max(fo, s.f_out);
+      for (const Step& s : lv.cf.steps) fo = std::max(fo, s.f_out);
+      fo = std::max(fo, lv.cf.Ca * 2);
+    }
+    int dense_hid = 0;     // DenseBlock coupling nets need a growth slab, FCN ones do not
+    for (const Level& lv : levels) {
+      for (const Step& s : lv.steps) if (!s.fcn) dense_hid = std::max(dense_hid, s.hid);
+      for (const Step& s : lv.cf.steps) if (!s.fcn) dense_hid = std::max(dense_hid, s.hid);
+    }
+    const int nf = cfg.rrdb_nf;
+    sc.h1 = alloc(B_, H, W, hid);
+    sc.h2 = alloc(B_, H, W, hid);
+    sc.hout = alloc(B_, H, W, fo);
+    sc.grow = alloc(B_, H, W, std::max(4, 4 * dense_hid));
+    sc.t1 = alloc(B_, H, W, nf);
+    sc.t2 = alloc(B_, H, W, nf);
+    sc.x = alloc(B_, H, W, nf);
+    sc.f0 = alloc(B_, H, W, nf);
+    sc.rgrow = alloc(B_, H, W, 4 * cfg.rrdb_gc);
+    return sc;
+  }
+
+  int ensure_arena(size_t need) {
+    if (need <= arena.cap) return HCF_OK;
+    if (arena.base) {
+      hipStreamSynchronize(st);
+      hipFree(arena.base);
+      arena.base = nullptr;
+      arena.cap = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return fail(HCF_ERR_NOMEM, "hipMalloc failed for the activation arena");
+    arena.base = (char*)p;
+    arena.cap = need;
+    return HCF_OK;
+  }
+
+  // ---------------------------------------------------------------- inverse pass
+  // FlowNet.reverse_flow (FlowNet_SR_x4.py:106-123, FlowNet_SR_x8.py:121-144, FlowNet_Rescaling_x4.py:111-128)
+  void pass_inverse(const float* lr, const float* const* eps, int n_eps, float tau, uint64_t seed, float* out, int B,
+                    int h, int w, uint32_t flags) {
+    B_ = B;
+    arena.top = 0;
+    const int L = cfg.L;
+    std::vector<Buf> cfb(L);
+    Buf zprev;       // z buffer of the level processed before (deeper)
+    zprev.p = nullptr;
+    for (int level = L - 1; level >= 0; --level) {
+      const Level& lv = levels[level];
+      const CondFlow& cf = lv.cf;
+      const int H = h << (L - 1 - level), W = w << (L - 1 - level);
+      cfb[level] = alloc(B, H, W, cond_ch());
+      Buf z = alloc(B, H, W, lv.C);
+      if (level == L - 1) {
+        HCF_LAUNCH(launch_nchw_to_nhwc(lr, z.v(0, 3), B, 3, H, W, st));
+      } else {
+        // squeeze^-1 of the deeper level lands in z[:, :ns]   (Basic.py:143-157 / :479-487)
+        const Level& dp = levels[level + 1];
+        if (cfg.squeeze == HCF_SQUEEZE_HAAR)
+          HCF_LAUNCH(launch_haar_inv(zprev.all(), z.v(0, lv.ns), B, dp.C, H / 2, W / 2, st));
+        else
+          HCF_LAUNCH(launch_unsqueeze(zprev.all(), z.v(0, lv.ns), B, dp.C, H / 2, W / 2, st));
+      }
+      const size_t mark = arena.top;
+      Scratch sc = alloc_scratch(H, W);
+      Buf a = alloc(B, H, W, cf.Ca);
+      // conditional features: u = cat(z, up2(cf_{l+1}), up4(cf_{l+2}))  (FlowNet_SR_x8.py:132-137)
+      std::vector<View> u;
+      u.push_back(z.v(0, lv.ns));
+      for (int l2 = level + 1; l2 < L; ++l2) u.push_back(cfb[l2].v(0, cond_ch(), l2 - level));
+      run_cond_features(cf, u, H, W, cfb[level], sc);
+      const View cfv = cfb[level].v(0, cond_ch());
+      // prior: a = mean + exp(logs) * eps   (ConditionalFlow.py:61-64 / 88-91)
+      run_conv(cf.head, {cfv}, H, W, sc.hout.v(0, cf.Ca * 2));
+      {
+        GaussArgs g;
+        memset(&g, 0, sizeof(g));
+        g.B = B; g.H = H; g.W = W; g.C = cf.Ca;
+        g.h = sc.hout.v(0, cf.Ca * 2);
+        g.rescale = sr() ? 0 : 1;
+        const int draw = L - 1 - level;
+        g.eps = (eps && draw < n_eps) ? eps[draw] : nullptr;
+        g.tau = tau; g.seed = seed; g.offset = (uint64_t)draw;
+        g.out = a.all();
+        HCF_LAUNCH(launch_gauss_sample(g, st));
+      }
+      for (int k = (int)cf.steps.size() - 1; k >= 0; --k) run_step_inverse(cf.steps[k], a, &cfv, H, W, sc);
+      // Split reverse: z = cat(z, a)   (Basic.py:498-499)
+      HCF_LAUNCH(launch_copy_view(a.all(), z.v(lv.ns, cf.Ca), B, H, W, st));
+      for (int k = (int)lv.steps.size() - 1; k >= 0; --k) run_step_inverse(lv.steps[k], z, nullptr, H, W, sc);
+      arena.top = mark;     // scratch of this level is dead; z and cf stay
+      zprev = z;
+      if (level == 0)
+        HCF_LAUNCH(launch_unsqueeze_nchw(z.all(), out, B, lv.C, H, W, cfg.squeeze == HCF_SQUEEZE_HAAR ? 1 : 0,
+                                         (flags & HCF_FLAG_NO_CLAMP) ? 0 : 1, st));
+    }
+  }
+
+  // ---------------------------------------------------------------- forward pass
+  // FlowNet.normal_flow (FlowNet_SR_x4.py:84-101, FlowNet_SR_x8.py:91-116, FlowNet_Rescaling_x4.py:89-106)
+  void pass_forward(const float* hr, const float* lr, const float* noise, float* out_lr, float* out_nll,
+                    float* out_logdet, float* out_z, float* out_z1, float* out_z2, int B, int H0, int W0, uint32_t flags) {
+    B_ = B;
+    arena.top = 0;
+    const int L = cfg.L;
+    const bool want_ld = sr();
+    // partial-sum slots
+    int nslots = 0;
+    double ld_const = sr() ? -log((double)cfg.quant) * (double)H0 * W0 : 0.0;
+    for (int level = 0; level < L; ++level) {
+      const int H = H0 >> (level + 1), W = W0 >> (level + 1);
+      const int nb = step_blocks_per_sample(H, W);
+      for (const Step& s : levels[level].steps) { if (s.mode == CPL_AFFINE) nslots += nb; ld_const += s.ld_const * H * W; }
+      for (const Step& s : levels[level].cf.steps) { if (s.mode == CPL_AFFINE) nslots += nb; ld_const += s.ld_const * H * W; }
+      nslots += nb;                      // gaussian logp
+    }
+    nslots += step_blocks_per_sample(H0 >> L, W0 >> L);   // Dirac term
+    float* partial = nullptr;
+    int pslot = 0;
+    if (want_ld) {
+      partial = arena.alloc((size_t)B * nslots);
+      HCF_LAUNCH(launch_fill(partial, (size_t)B * nslots, 0.f, st));
+    }
+    std::vector<Buf> zb(L), cfb(L);
+    for (int level = 0; level < L; ++level) {
+      const Level& lv = levels[level];
+      const int H = H0 >> (level + 1), W = W0 >> (level + 1);
+      zb[level] = alloc(B, H, W, lv.C);
+      cfb[level] = alloc(B, H, W, cond_ch());
+      if (level == 0) {
+        HCF_LAUNCH(launch_nchw_squeeze(hr, noise, cfg.quant, zb[0].all(), B, cfg.in_nc, H0, W0,
+                                       cfg.squeeze == HCF_SQUEEZE_HAAR ? 1 : 0, st));
+      } else {
+        const Level& up = levels[level - 1];
+        if (cfg.squeeze == HCF_SQUEEZE_HAAR)
+          HCF_LAUNCH(launch_haar_fwd(zb[level - 1].v(0, up.ns), zb[level].all(), B, up.ns, H * 2, W * 2, st));
+        else
+          HCF_LAUNCH(launch_squeeze(zb[level - 1].v(0, up.ns), zb[level].all(), B, up.ns, H * 2, W * 2, st));
+      }
+      const size_t mark = arena.top;
+      Scratch sc = alloc_scratch(H, W);
+      for (size_t k = 0; k < lv.steps.size(); ++k)
+        run_step_forward(lv.steps[k], zb[level], nullptr, H, W, sc, partial, nslots, pslot);
+      arena.top = mark;
+    }
+    // hierarchical conditional prior, deepest level first (FlowNet_SR_x4.py:95-99)
+    for (int level = L - 1; level >= 0; --level) {
+      const Level& lv = levels[level];
+      const CondFlow& cf = lv.cf;
+      const int H = H0 >> (level + 1), W = W0 >> (level + 1);
+      const size_t mark = arena.top;
+      Scratch sc = alloc_scratch(H, W);
+      Buf a = alloc(B, H, W, cf.Ca);
+      std::vector<View> u;
+      u.push_back(zb[level].v(0, lv.ns));
+      for (int l2 = level + 1; l2 < L; ++l2) u.push_back(cfb[l2].v(0, cond_ch(), l2 - level));
+      run_cond_features(cf, u, H, W, cfb[level], sc);
+      const View cfv = cfb[level].v(0, cond_ch());
+      HCF_LAUNCH(launch_copy_view(zb[level].v(lv.ns, cf.Ca), a.all(), B, H, W, st));
+      for (size_t k = 0; k < cf.steps.size(); ++k) run_step_forward(cf.steps[k], a, &cfv, H, W, sc, partial, nslots, pslot);
+      run_conv(cf.head, {cfv}, H, W, sc.hout.v(0, cf.Ca * 2));
+      GaussArgs g;
+      memset(&g, 0, sizeof(g));
+      g.B = B; g.H = H; g.W = W; g.C = cf.Ca;
+      g.h = sc.hout.v(0, cf.Ca * 2);
+      g.out = a.all();
+      if (sr()) {
+        g.partial = partial + pslot;
+        g.partial_stride = nslots;
+        pslot += step_blocks_per_sample(H, W);
+        HCF_LAUNCH(launch_gauss_logp(g, st));
+      } else {
+        g.rescale = 1;
+        g.aux = (level == 0) ? out_z1 : out_z2;
+        if (g.aux) HCF_LAUNCH(launch_gauss_encode(g, st));
+      }
+      arena.top = mark;
+    }
+    const int h = H0 >> L, w = W0 >> L;
+    const View zlr = zb[L - 1].v(0, 3);
+    if (sr()) {
+      if (out_z) HCF_LAUNCH(launch_nhwc_to_nchw(zlr, out_z, B, 3, h, w, 0, st));
+      float* pp = partial + pslot;
+      pslot += step_blocks_per_sample(h, w);
+      HCF_LAUNCH(launch_quant_logp(zlr, lr, out_lr, B, h, w, lr ? pp : nullptr, nslots, st));
+      if (pslot > nslots) fail(HCF_ERR_STATE, "internal: partial slot overflow");
+      HCF_LAUNCH(launch_reduce_partials(partial, nslots, nslots, B, ld_const, (double)H0 * W0, out_logdet, out_nll, st));
+    } else {
+      HCF_LAUNCH(launch_nhwc_to_nchw(zlr, out_lr, B, 3, h, w, (flags & HCF_FLAG_NO_CLAMP) ? 0 : 1, st));
+    }
+  }
+
+  template <class F>
+  int run_pass(F&& body, hipStream_t stream) {
+    if (!finalized) return fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
+    if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
+    rc = HCF_OK;
+    st = stream;
+    arena.dry = true;
+    arena.peak = 0;
+    body();
+    arena.dry = false;
+    if (rc != HCF_OK) return rc;
+    if (ensure_arena(arena.peak) != HCF_OK) return rc;
+    body();
+    return rc;
+  }
+};
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int hcf_create(const hcf_config* cfg, hcf_engine** out) {
+  if (!cfg || !out) return HCF_ERR_ARG;
+  *out = nullptr;
+  if (cfg->L < 2 || cfg->L > 3 || (1 << cfg->L) != cfg->scale || cfg->in_nc != 3) return HCF_ERR_UNSUPPORTED;
+  if (cfg->kind != HCF_KIND_SR && cfg->kind != HCF_KIND_RESCALING) return HCF_ERR_ARG;
+  if (cfg->kind == HCF_KIND_RESCALING && cfg->L != 2) return HCF_ERR_UNSUPPORTED;
+  if (cfg->rrdb_nf < 4 || cfg->rrdb_nf > 96 || cfg->rrdb_gc < 1 || cfg->rrdb_gc > 96 || cfg->hidden < 1 ||
+      cfg->hidden > 96 || cfg->c_hidden < 1 || cfg->c_hidden > 96 || (cfg->rrdb_nf & 3) || (cfg->rrdb_gc & 3) ||
+      (cfg->hidden & 3) || (cfg->c_hidden & 3))
+    return HCF_ERR_UNSUPPORTED;
+  for (int l = 0; l < cfg->L; ++l)
+    if (cfg->after[l] < 0 || cfg->after[l] > cfg->K[l]) return HCF_ERR_ARG;
+  hcf_engine* e = new (std::nothrow) hcf_engine();
+  if (!e) return HCF_ERR_NOMEM;
+  e->cfg = *cfg;
+  e->spec_mode = true;
+  e->rc = HCF_OK;
+  const int r = e->build();
+  if (r != HCF_OK) { delete e; return r; }
+  for (const Spec& s : e->specs) {
+    HostTensor t;
+    t.shape = s.shape;
+    e->params[s.key] = t;
+  }
+  *out = e;
+  return HCF_OK;
+}
+
+void hcf_destroy(hcf_engine* e) {
+  if (!e) return;
+  if (e->device >= 0) hipSetDevice(e->device);
+  e->free_weights();
+  if (e->arena.base) hipFree(e->arena.base);
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  delete e;
+}
+
+const char* hcf_last_error(const hcf_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int hcf_param_count(const hcf_engine* e) { return e ? (int)e->specs.size() : HCF_ERR_ARG; }
+
+int hcf_param_info(const hcf_engine* e, int index, const char** key, int32_t* ndim, int64_t shape[4]) {
+  if (!e || index < 0 || index >= (int)e->specs.size()) return HCF_ERR_ARG;
+  const Spec& s = e->specs[index];
+  if (key) *key = s.key.c_str();
+  if (ndim) *ndim = (int32_t)s.shape.size();
+  if (shape)
+    for (size_t i = 0; i < 4; ++i) shape[i] = i < s.shape.size() ? s.shape[i] : 1;
+  return HCF_OK;
+}
+
+int hcf_set_param(hcf_engine* e, const char* key, const float* host_data, const int64_t* shape, int32_t ndim) {
+  if (!e || !key || !host_data || !shape || ndim < 1 || ndim > 4) return HCF_ERR_ARG;
+  auto it = e->params.find(key);
+  if (it == e->params.end()) return e->fail(HCF_ERR_KEY, std::string("unexpected key in state_dict: ") + key), HCF_ERR_KEY;
+  HostTensor& t = it->second;
+  if ((int)t.shape.size() != ndim) return e->fail(HCF_ERR_SHAPE, std::string("size mismatch for ") + key), HCF_ERR_SHAPE;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (t.shape[i] != shape[i]) return e->fail(HCF_ERR_SHAPE, std::string("size mismatch for ") + key), HCF_ERR_SHAPE;
+    n *= (size_t)shape[i];
+  }
+  t.data.assign(host_data, host_data + n);
+  t.set = true;
+  e->finalized = false;
+  return HCF_OK;
+}
+
+int hcf_finalize(hcf_engine* e, int device) {
+  if (!e) return HCF_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return e->fail(HCF_ERR_HIP, "hipSetDevice failed (no GPU?)");
+  if (e->device >= 0 && e->device != device && e->arena.base) {
+    hipSetDevice(e->device);
+    hipFree(e->arena.base);
+    e->arena.base = nullptr;
+    e->arena.cap = 0;
+    hipSetDevice(device);
+  }
+  hipDeviceSynchronize();      // packed weights of a previous finalize may still be in use
+  e->free_weights();
+  e->device = device;
+  e->spec_mode = false;
+  e->rc = HCF_OK;
+  e->err.clear();
+  const int r = e->build();
+  if (r != HCF_OK) { e->free_weights(); return r; }
+  e->finalized = true;
+  return HCF_OK;
+}
+
+int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream) {
+  if (!e || !lr || !out_hr || B < 1 || h < 1 || w < 1) return HCF_ERR_ARG;
+  return e->run_pass([&]() { e->pass_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags); }, (hipStream_t)stream);
+}
+
+int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr, float* out_nll,
+                   float* out_logdet, float* out_z, int32_t B, int32_t H, int32_t W, hcf_stream_t stream) {
+  if (!e || !hr || B < 1 || H < 1 || W < 1) return HCF_ERR_ARG;
+  if (e->cfg.kind != HCF_KIND_SR) return e->fail(HCF_ERR_STATE, "hcf_forward_sr on a rescaling engine"), HCF_ERR_STATE;
+  const int m = 1 << e->cfg.L;
+  if (H % m || W % m) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by the scale (squeeze2d assert, Basic.py:136)"), HCF_ERR_SHAPE;
+  return e->run_pass([&]() { e->pass_forward(hr, lr, noise, out_lr, out_nll, out_logdet, out_z, nullptr, nullptr, B, H, W, 0); },
+                     (hipStream_t)stream);
+}
+
+int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B, int32_t H,
+                        int32_t W, uint32_t flags, hcf_stream_t stream) {
+  if (!e || !hr || !out_lr || B < 1 || H < 1 || W < 1) return HCF_ERR_ARG;
+  if (e->cfg.kind != HCF_KIND_RESCALING) return e->fail(HCF_ERR_STATE, "hcf_forward_rescale on an SR engine"), HCF_ERR_STATE;
+  const int m = 1 << e->cfg.L;
+  if (H % m || W % m) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by 4"), HCF_ERR_SHAPE;
+  return e->run_pass([&]() { e->pass_forward(hr, nullptr, nullptr, out_lr, nullptr, nullptr, nullptr, out_z1, out_z2, B, H, W, flags); },
+                     (hipStream_t)stream);
+}
+
+size_t hcf_workspace_bytes(const hcf_engine* e) { return e ? e->arena.cap : 0; }
+size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }
+
+int hcf_profile_convs(hcf_engine* e, int enable) {
+  if (!e) return HCF_ERR_ARG;
+  e->prof = enable != 0;
+  e->prof_used = 0;
+  e->prof_flops = 0;
+  return HCF_OK;
+}
+
+int hcf_conv_time_ms(hcf_engine* e, double* total_ms, int64_t* launches, double* flops) {
+  if (!e) return HCF_ERR_ARG;
+  double tot = 0;
+  for (size_t i = 0; i < e->prof_used; ++i) {
+    if (hipEventSynchronize(e->prof_events[i].second) != hipSuccess) return HCF_ERR_HIP;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second) != hipSuccess) return HCF_ERR_HIP;
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)e->prof_used;
+  if (flops) *flops = e->prof_flops;
+  e->prof_used = 0;
+  e->prof_flops = 0;
+  return HCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// Flow-step glue and boundary kernels (HBM-bound, < 1 % of the FLOPs; SURVEY.md 8a rows a4-a8,
+// a13-a18). One thread per pixel: a pixel's channel vector (<= 48 floats) lives in registers,
+// ActNorm + invertible 1x1 conv + affine coupling are fused into a single pass over z, the C x C
+// matrices are wave-uniform (scalar loads, SGPR operands of v_fma). Per-sample log-det sums use
+// wave shuffles -> LDS -> one partial per block (deterministic; reduced later in double).
+#include "hcf_common.h"
+
+namespace hcf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// sum over the 256-thread block; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  return r;
+}
+
+__device__ __forceinline__ float logscale_of(float s) {
+  // 0.318 * atan(2 * scale)   (AffineCouplings.py:53,83)
+  return 0.318f * atanf(2.f * s);
+}
+
+template <int CMAX>
+__device__ __forceinline__ void load_pixel(const View& v, size_t pix, int C, float (&z)[CMAX]) {
+  const float* p = v.p + pix * v.cs + v.c0;
+  if (((v.cs | v.c0) & 3) == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < CMAX / 4; ++c4) {
+      if (4 * c4 < C) {                      // cs = roundup4(C): the whole float4 is inside the pixel
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * c4);
+        z[4 * c4 + 0] = t.x;
+        z[4 * c4 + 1] = (4 * c4 + 1 < C) ? t.y : 0.f;
+        z[4 * c4 + 2] = (4 * c4 + 2 < C) ? t.z : 0.f;
+        z[4 * c4 + 3] = (4 * c4 + 3 < C) ? t.w : 0.f;
+      } else {
+        z[4 * c4 + 0] = 0.f; z[4 * c4 + 1] = 0.f; z[4 * c4 + 2] = 0.f; z[4 * c4 + 3] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? p[c] : 0.f;
+  }
+}
+
+template <int CMAX>
+__device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, const float (&z)[CMAX]) {
+  float* p = v.p + pix * v.cs + v.c0;
+  if (((v.cs | v.c0) & 3) == 0 && (C & 3) == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < CMAX / 4; ++c4)
+      if (4 * c4 < C) {
+        f32x4 t = {z[4 * c4], z[4 * c4 + 1], z[4 * c4 + 2], z[4 * c4 + 3]};
+        *reinterpret_cast<f32x4*>(p + 4 * c4) = t;
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) p[c] = z[c];
+  }
+}
+
+// y = M z with M row-major [CMAX][CMAX] (host pads rows/cols beyond C with zeros)
+template <int CMAX>
+__device__ __forceinline__ void matvec(const float* __restrict__ M, const float (&z)[CMAX], float (&y)[CMAX]) {
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) acc = fmaf(M[c * CMAX + k], z[k], acc);
+    y[c] = acc;
+  }
+}
+
+// ---- inverse flow step tail: coupling^-1 -> W^-1 -> actnorm^-1  (FlowStep.py:53-64) -----------
+template <int CMAX>
+__global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  float z[CMAX];
+  load_pixel<CMAX>(a.z, pix, a.C, z);
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  if (a.mode == CPL_AFFINE) {
+    // z2 = z2 * exp(-logscale) - shift, (shift, scale) = h[0::2], h[1::2]  (AffineCouplings.py:65-87)
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c >= a.ns && c < a.C) {
+        const int j = c - a.ns;
+        const float shift = hp[2 * j], scale = hp[2 * j + 1];
+        z[c] = z[c] * expf(-logscale_of(scale)) - shift;
+      }
+    }
+  } else {
+    // AffineCoupling3shift, LRvsothers=False: z[:3] -= f(z[3:])  (AffineCouplings.py:150-153)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[c] = z[c] - hp[c];
+  }
+  float y[CMAX];
+  if (a.mat) {
+    matvec<CMAX>(a.mat, z, y);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) y[c] = z[c];
+  }
+  // actnorm reverse: x * exp(-logs) - bias  (ActNorms.py:54,66)
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) y[c] = y[c] * a.an_mul[c] - a.an_bias[c];
+  store_pixel<CMAX>(a.out, pix, a.C, y);
+}
+
+// ---- forward flow step head: actnorm -> W  (FlowStep.py:40-47) --------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void step_head_fwd_kernel(const StepArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  float z[CMAX];
+  load_pixel<CMAX>(a.z, pix, a.C, z);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) z[c] = (z[c] + a.an_bias[c]) * a.an_mul[c];   // (x + b) * exp(logs)
+  if (a.mat) {
+    float y[CMAX];
+    matvec<CMAX>(a.mat, z, y);
+    store_pixel<CMAX>(a.out, pix, a.C, y);
+  } else {
+    store_pixel<CMAX>(a.out, pix, a.C, z);
+  }
+}
+
+// ---- forward coupling: z2 = (z2 + shift) * exp(logscale), partial += sum(logscale) ------------
+__global__ __launch_bounds__(256) void step_couple_fwd_kernel(const StepArgs a) {
+  __shared__ float sh[4];
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float lsum = 0.f;
+  if (i < hw) {
+    const size_t pix = (size_t)blockIdx.y * hw + i;
+    const float* zp = a.z.p + pix * a.z.cs + a.z.c0;
+    float* op = a.out.p + pix * a.out.cs + a.out.c0;
+    const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+    if (a.mode == CPL_AFFINE) {
+      if (op != zp)
+        for (int c = 0; c < a.ns; ++c) op[c] = zp[c];
+      for (int c = a.ns; c < a.C; ++c) {
+        const int j = c - a.ns;
+        const float ls = logscale_of(hp[2 * j + 1]);
+        op[c] = (zp[c] + hp[2 * j]) * expf(ls);
+        lsum += ls;
+      }
+    } else {
+      for (int c = 0; c < 3; ++c) op[c] = zp[c] + hp[c];
+      if (op != zp)
+        for (int c = 3; c < a.C; ++c) op[c] = zp[c];
+    }
+  }
+  if (a.partial) {
+    const float s = block_sum(lsum, sh);
+    if (threadIdx.x == 0) a.partial[(size_t)blockIdx.y * a.partial_stride + blockIdx.x] = s;
+  }
+}
+
+int step_blocks_per_sample(int H, int W) { return (H * W + 255) / 256; }
+
+#define HCF_DISPATCH_CMAX(KERNEL, A, ST)                                                       \
+  do {                                                                                         \
+    const dim3 grid((unsigned)step_blocks_per_sample((A).H, (A).W), (unsigned)(A).B);          \
+    if ((A).C <= 8) hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, ST, A);                \
+    else if ((A).C <= 12) hipLaunchKernelGGL((KERNEL<12>), grid, dim3(256), 0, ST, A);         \
+    else if ((A).C <= 24) hipLaunchKernelGGL((KERNEL<24>), grid, dim3(256), 0, ST, A);         \
+    else if ((A).C <= 48) hipLaunchKernelGGL((KERNEL<48>), grid, dim3(256), 0, ST, A);         \
+    else return HCF_ERR_UNSUPPORTED;                                                           \
+  } while (0)
+
+int step_cmax(int C) { return C <= 8 ? 8 : C <= 12 ? 12 : C <= 24 ? 24 : C <= 48 ? 48 : -1; }
+
+int launch_step_tail_inv(const StepArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1) return HCF_ERR_ARG;
+  HCF_DISPATCH_CMAX(step_tail_inv_kernel, a, st);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+int launch_step_head_fwd(const StepArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1) return HCF_ERR_ARG;
+  HCF_DISPATCH_CMAX(step_head_fwd_kernel, a, st);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+int launch_step_couple_fwd(const StepArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1) return HCF_ERR_ARG;
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  hipLaunchKernelGGL(step_couple_fwd_kernel, grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+// ---- Philox4x32-10 + Box-Muller (device-side eps for perf runs; parity runs inject eps) -------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+  const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// ---- Gaussian prior ---------------------------------------------------------------------------
+// sample: a = mean + exp(logs) * eps,  (mean, s) = h[0::2], h[1::2]   (Basic.py:96-101,
+// ConditionalFlow.py:61-64 SR, :88-91 rescaling with logs = 0.318 atan(2 s))
+__global__ __launch_bounds__(256) void gauss_sample_kernel(const GaussArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y;
+  const size_t pix = (size_t)b * hw + i;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  float* op = a.out.p + pix * a.out.cs + a.out.c0;
+  for (int c = 0; c < a.C; ++c) {
+    const float mean = hp[2 * c], s = hp[2 * c + 1];
+    const float logs = a.rescale ? logscale_of(s) : s;
+    const size_t e = ((size_t)b * a.C + c) * hw + i;           // NCHW element index
+    float eps;
+    if (a.eps) eps = a.eps[e];
+    else eps = (a.tau == 0.f) ? 0.f : a.tau * philox_normal(a.seed, a.offset, e);
+    op[c] = mean + expf(logs) * eps;
+  }
+}
+
+// logp: sum -0.5 (2 logs + (x - mean)^2 / exp(2 logs) + ln 2pi)   (Basic.py:78-94)
+__global__ __launch_bounds__(256) void gauss_logp_kernel(const GaussArgs a) {
+  __shared__ float sh[4];
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (i < hw) {
+    const size_t pix = (size_t)blockIdx.y * hw + i;
+    const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+    const float* xp = a.out.p + pix * a.out.cs + a.out.c0;
+    for (int c = 0; c < a.C; ++c) {
+      const float mean = hp[2 * c], logs = hp[2 * c + 1];
+      const float d = xp[c] - mean;
+      acc += -0.5f * (logs * 2.f + (d * d) / expf(logs * 2.f) + 1.8378770664093453f);
+    }
+  }
+  const float s = block_sum(acc, sh);
+  if (threadIdx.x == 0) a.partial[(size_t)blockIdx.y * a.partial_stride + blockIdx.x] = s;
+}
+
+// rescaling forward: z = (a - mean) * exp(-logscale) -> NCHW   (ConditionalFlow.py:76-80)
+__global__ __launch_bounds__(256) void gauss_encode_kernel(const GaussArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y;
+  const size_t pix = (size_t)b * hw + i;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  const float* xp = a.out.p + pix * a.out.cs + a.out.c0;
+  for (int c = 0; c < a.C; ++c) {
+    const float mean = hp[2 * c], ls = logscale_of(hp[2 * c + 1]);
+    a.aux[((size_t)b * a.C + c) * hw + i] = (xp[c] - mean) * expf(-ls);
+  }
+}
+
+static inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
+
+int launch_gauss_sample(const GaussArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(gauss_sample_kernel, pix_grid(a.B, a.H, a.W), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+int launch_gauss_logp(const GaussArgs& a, hipStream_t st) {
+  if (!a.partial) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(gauss_logp_kernel, pix_grid(a.B, a.H, a.W), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+int launch_gauss_encode(const GaussArgs& a, hipStream_t st) {
+  if (!a.aux) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(gauss_encode_kernel, pix_grid(a.B, a.H, a.W), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+// ---- layout / squeeze / Haar ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, View dst, int C, int hw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y;
+  float* op = dst.p + ((size_t)b * hw + i) * dst.cs + dst.c0;
+  for (int c = 0; c < C; ++c) op[c] = src[((size_t)b * C + c) * hw + i];
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(View src, float* dst, int C, int hw, int clamp01) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y;
+  const float* ip = src.p + ((size_t)b * hw + i) * src.cs + src.c0;
+  for (int c = 0; c < C; ++c) {
+    float v = ip[c];
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    dst[((size_t)b * C + c) * hw + i] = v;
+  }
+}
+
+// Haar signs s_k(i,j), k = LL,HL,LH,HH (Basic.py:455-464)
+__device__ __forceinline__ float haar_sign(int k, int i, int j) {
+  const bool neg = (k == 1 && j == 1) || (k == 2 && i == 1) || (k == 3 && (i != j));
+  return neg ? -1.f : 1.f;
+}
+
+// in [B,H,W,C] -> out [B,H/2,W/2,4C]; one thread per OUTPUT pixel
+__global__ __launch_bounds__(256) void squeeze_kernel(View in, View out, int C, int H, int W, int haar) {
+  const int H2 = H >> 1, W2 = W >> 1, hw2 = H2 * W2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw2) return;
+  const int b = blockIdx.y, h = i / W2, w = i - h * W2;
+  float* op = out.p + ((size_t)b * hw2 + i) * out.cs + out.c0;
+  const float* ip[2][2];
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+      ip[di][dj] = in.p + ((size_t)((size_t)b * H + 2 * h + di) * W + 2 * w + dj) * in.cs + in.c0;
+  for (int c = 0; c < C; ++c) {
+    const float v00 = ip[0][0][c], v01 = ip[0][1][c], v10 = ip[1][0][c], v11 = ip[1][1][c];
+    if (!haar) {
+      op[c * 4 + 0] = v00; op[c * 4 + 1] = v01; op[c * 4 + 2] = v10; op[c * 4 + 3] = v11;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        op[k * C + c] = (((v00 * haar_sign(k, 0, 0) + v01 * haar_sign(k, 0, 1)) + v10 * haar_sign(k, 1, 0)) +
+                         v11 * haar_sign(k, 1, 1)) / 4.0f;
+    }
+  }
+}
+
+// in [B,H,W,C4] -> out [B,2H,2W,C4/4]; one thread per INPUT pixel
+__global__ __launch_bounds__(256) void unsqueeze_kernel(View in, View out, int C4, int H, int W, int haar) {
+  const int hw = H * W, C = C4 >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y, h = i / W, w = i - h * W;
+  const float* ip = in.p + ((size_t)b * hw + i) * in.cs + in.c0;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj) {
+      float* op = out.p + ((size_t)((size_t)b * 2 * H + 2 * h + di) * (2 * W) + 2 * w + dj) * out.cs + out.c0;
+      for (int c = 0; c < C; ++c) {
+        if (!haar) op[c] = ip[c * 4 + di * 2 + dj];
+        else
+          op[c] = ((ip[c] * haar_sign(0, di, dj) + ip[C + c] * haar_sign(1, di, dj)) + ip[2 * C + c] * haar_sign(2, di, dj)) +
+                  ip[3 * C + c] * haar_sign(3, di, dj);
+      }
+    }
+}
+
+// NCHW (+ dequantisation noise) -> squeeze/haar -> NHWC   (HCFlowNet_SR_arch.py:52 + first layer)
+__global__ __launch_bounds__(256) void nchw_squeeze_kernel(const float* src, const float* noise, float quant,
+                                                          View out, int C, int H, int W, int haar) {
+  const int H2 = H >> 1, W2 = W >> 1, hw2 = H2 * W2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw2) return;
+  const int b = blockIdx.y, h = i / W2, w = i - h * W2;
+  float* op = out.p + ((size_t)b * hw2 + i) * out.cs + out.c0;
+  for (int c = 0; c < C; ++c) {
+    float v[2][2];
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const size_t e = ((size_t)((size_t)b * C + c) * H + 2 * h + di) * W + 2 * w + dj;
+        float t = src[e];
+        if (noise) t = t + noise[e] / quant;         // hr + rand / quant (HCFlowNet_SR_arch.py:52)
+        v[di][dj] = t;
+      }
+    if (!haar) {
+      op[c * 4 + 0] = v[0][0]; op[c * 4 + 1] = v[0][1]; op[c * 4 + 2] = v[1][0]; op[c * 4 + 3] = v[1][1];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        op[k * C + c] = (((v[0][0] * haar_sign(k, 0, 0) + v[0][1] * haar_sign(k, 0, 1)) + v[1][0] * haar_sign(k, 1, 0)) +
+                         v[1][1] * haar_sign(k, 1, 1)) / 4.0f;
+    }
+  }
+}
+
+// NHWC [B,H,W,C4] -> unsqueeze/haar^-1 -> (clamp) -> NCHW [B,C4/4,2H,2W]
+__global__ __launch_bounds__(256) void unsqueeze_nchw_kernel(View in, float* dst, int C4, int H, int W, int haar,
+                                                            int clamp01) {
+  const int hw = H * W, C = C4 >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const int b = blockIdx.y, h = i / W, w = i - h * W;
+  const float* ip = in.p + ((size_t)b * hw + i) * in.cs + in.c0;
+  for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        float v;
+        if (!haar) v = ip[c * 4 + di * 2 + dj];
+        else
+          v = ((ip[c] * haar_sign(0, di, dj) + ip[C + c] * haar_sign(1, di, dj)) + ip[2 * C + c] * haar_sign(2, di, dj)) +
+              ip[3 * C + c] * haar_sign(3, di, dj);
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[((size_t)((size_t)b * C + c) * (2 * H) + 2 * h + di) * (2 * W) + 2 * w + dj] = v;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_view_kernel(View in, View out, int hw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* ip = in.p + pix * in.cs + in.c0;
+  float* op = out.p + pix * out.cs + out.c0;
+  for (int c = 0; c < in.n; ++c) op[c] = ip[c];
+}
+
+// Quant (Basic.py:187-191) + logp(lr, logs=-6, zq) (HCFlowNet_SR_arch.py:58-63); z has 3 channels
+__global__ __launch_bounds__(256) void quant_logp_kernel(View z, const float* lr, float* lr_hat, int C, int hw,
+                                                        float* partial, int partial_stride) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  float acc = 0.f;
+  if (i < hw) {
+    const float* zp = z.p + ((size_t)b * hw + i) * z.cs + z.c0;
+    for (int c = 0; c < C; ++c) {
+      const float zc = fminf(fmaxf(zp[c], 0.f), 1.f);
+      const float zq = rintf(zc * 255.f) / 255.f;
+      const size_t e = ((size_t)b * C + c) * hw + i;
+      if (lr_hat) lr_hat[e] = fminf(fmaxf(zq, 0.f), 1.f);
+      if (lr) {
+        const float logs = -6.f;
+        const float d = zq - lr[e];
+        acc += -0.5f * (logs * 2.f + (d * d) / expf(logs * 2.f) + 1.8378770664093453f);
+      }
+    }
+  }
+  if (partial) {
+    const float s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(size_t)b * partial_stride + blockIdx.x] = s;
+  }
+}
+
+// out[b] = cst + sum_j partial[b][j] in double; nll = mean_b(-out[b]) / (ln2 * pixels)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int stride, int n, int B, double cst,
+                                                             double pixels, float* out_logdet, float* out_nll) {
+  __shared__ double shd[4];
+  double nll = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) acc += (double)partial[(size_t)b * stride + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double tot = cst + shd[0] + shd[1] + shd[2] + shd[3];
+      if (out_logdet) out_logdet[b] = (float)tot;
+      nll += -tot / (0.6931471805599453 * pixels);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && out_nll) out_nll[0] = (float)(nll / B);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+#define HCF_RET() return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP
+
+int launch_nchw_to_nhwc(const float* src, View dst, int B, int C, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, pix_grid(B, H, W), dim3(256), 0, st, src, dst, C, H * W);
+  HCF_RET();
+}
+int launch_nhwc_to_nchw(View src, float* dst, int B, int C, int H, int W, int clamp01, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, pix_grid(B, H, W), dim3(256), 0, st, src, dst, C, H * W, clamp01);
+  HCF_RET();
+}
+int launch_squeeze(View in, View out, int B, int C, int H, int W, hipStream_t st) {
+  if ((H | W) & 1) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(squeeze_kernel, pix_grid(B, H / 2, W / 2), dim3(256), 0, st, in, out, C, H, W, 0);
+  HCF_RET();
+}
+int launch_unsqueeze(View in, View out, int B, int C4, int H, int W, hipStream_t st) {
+  if (C4 & 3) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(unsqueeze_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, C4, H, W, 0);
+  HCF_RET();
+}
+int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t st) {
+  if ((H | W) & 1) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(squeeze_kernel, pix_grid(B, H / 2, W / 2), dim3(256), 0, st, in, out, C, H, W, 1);
+  HCF_RET();
+}
+int launch_haar_inv(View in, View out, int B, int C4, int H, int W, hipStream_t st) {
+  if (C4 & 3) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(unsqueeze_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, C4, H, W, 1);
+  HCF_RET();
+}
+int launch_nchw_squeeze(const float* src, const float* noise, float quant, View out, int B, int C, int H, int W,
+                        int haar, hipStream_t st) {
+  if ((H | W) & 1) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(nchw_squeeze_kernel, pix_grid(B, H / 2, W / 2), dim3(256), 0, st, src, noise, quant, out, C, H,
+                     W, haar);
+  HCF_RET();
+}
+int launch_unsqueeze_nchw(View in, float* dst, int B, int C4, int H, int W, int haar, int clamp01, hipStream_t st) {
+  if (C4 & 3) return HCF_ERR_SHAPE;
+  hipLaunchKernelGGL(unsqueeze_nchw_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, dst, C4, H, W, haar, clamp01);
+  HCF_RET();
+}
+int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st) {
+  hipLaunchKernelGGL(copy_view_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, H * W);
+  HCF_RET();
+}
+int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W, float* partial,
+                      int partial_stride, hipStream_t st) {
+  hipLaunchKernelGGL(quant_logp_kernel, pix_grid(B, H, W), dim3(256), 0, st, z, lr_nchw, lr_hat_nchw, z.n, H * W,
+                     partial, partial_stride);
+  HCF_RET();
+}
+int launch_reduce_partials(const float* partial, int stride, int n, int B, double cst, double pixels, float* out_logdet,
+                           float* out_nll, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, partial, stride, n, B, cst, pixels, out_logdet,
+                     out_nll);
+  HCF_RET();
+}
+int launch_fill(float* p, size_t n, float v, hipStream_t st) {
+  if (n == 0) return HCF_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  HCF_RET();
+}
+
+}  // namespace hcf

@@ -1,0 +1,161 @@
+/* hcflow.h -- C ABI of the MI355X-native HCFlow forward / inverse engine (libhcflow_hip.so).
+ *
+ * The reference (JingyunLiang/HCFlow) is pure PyTorch: its drop-in boundary is the Python class
+ * looked up by codes/models/networks.py:36-41 (define_G -> HCFlowNet_SR / HCFlowNet_Rescaling with
+ * forward(hr, lr, z, u, eps_std, add_gt_noise, step, reverse, training),
+ * codes/models/modules/HCFlowNet_SR_arch.py:34-42, HCFlowNet_Rescaling_arch.py:26-36). There is no
+ * FFI in the reference, so this C ABI sits directly beneath that class: hcflow_amd/arch.py keeps
+ * the reference's module surface and state_dict and forwards every call to the entry points
+ * below (last row). Each entry point names the reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes, no torch types. Return 0 on success, a negative HCF_ERR_*
+ * code otherwise (never throws); hcf_last_error() gives a message. Image tensors are dense NCHW
+ * fp32 DEVICE pointers owned by the caller; parameters are passed as HOST pointers and packed /
+ * uploaded by hcf_finalize(). All work is enqueued on the caller's HIP stream; no hidden device
+ * synchronisation happens inside hcf_inverse / hcf_forward_* once the workspace has reached its
+ * steady-state size (first call per shape may allocate).
+ */
+#ifndef HCFLOW_H_
+#define HCFLOW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCF_OK 0
+#define HCF_ERR_ARG (-1)
+#define HCF_ERR_HIP (-2)
+#define HCF_ERR_STATE (-3)
+#define HCF_ERR_KEY (-4)
+#define HCF_ERR_SHAPE (-5)
+#define HCF_ERR_UNSUPPORTED (-6)
+#define HCF_ERR_NOMEM (-7)
+
+/* enum values used in hcf_config */
+#define HCF_KIND_SR 0
+#define HCF_KIND_RESCALING 1
+#define HCF_SQUEEZE_CHECKERBOARD 0
+#define HCF_SQUEEZE_HAAR 1
+#define HCF_PERM_INVCONV 0
+#define HCF_PERM_NONE 1
+#define HCF_COUPLING_AFFINE 0
+#define HCF_COUPLING_AFFINE3SHIFT 1
+#define HCF_NN_FCN 0
+#define HCF_NN_DENSEBLOCK 1
+
+/* flags for hcf_inverse / hcf_forward_* */
+#define HCF_FLAG_NO_CLAMP 1u      /* return the flow output before torch.clamp(.,0,1) (parity tests) */
+
+typedef void* hcf_stream_t;        /* a hipStream_t */
+typedef struct hcf_engine hcf_engine;
+
+/* The yml network_G block as the reference reads it in FlowNet.__init__
+ * (FlowNet_SR_x4.py:17-27, FlowNet_SR_x8.py, FlowNet_Rescaling_x4.py:15-29) and
+ * ConditionalFlow.__init__ (ConditionalFlow.py:15-41). */
+typedef struct hcf_config {
+  int32_t kind;             /* HCF_KIND_* : HCFlowNet_SR or HCFlowNet_Rescaling */
+  int32_t scale;            /* 4 or 8 (= 2^L) */
+  int32_t in_nc;            /* network_G.in_nc (3) */
+  float quant;              /* opt.quant (SR) / datasets.train.quant (rescaling) */
+  int32_t L;                /* flowDownsampler.L : 2 or 3 */
+  int32_t K[4];             /* flowDownsampler.K per level */
+  int32_t after[4];         /* splitOff.after_flowstep per level */
+  int32_t squeeze;          /* HCF_SQUEEZE_* */
+  int32_t perm, coupling, nn_module, hidden;          /* main flow steps */
+  int32_t c_perm, c_coupling, c_nn_module, c_hidden;  /* conditional (splitOff) flow steps */
+  int32_t rrdb_nb[2];
+  int32_t rrdb_nf, rrdb_gc;
+} hcf_config;
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+/* Replaces HCFlowNet_SR.__init__ / HCFlowNet_Rescaling.__init__ -> FlowNet.__init__
+ * (HCFlowNet_SR_arch.py:12-31). Touches no device. */
+int hcf_create(const hcf_config* cfg, hcf_engine** out);
+void hcf_destroy(hcf_engine* e);
+const char* hcf_last_error(const hcf_engine* e);
+
+/* state_dict introspection: the keys / shapes the reference modules register, in registration
+ * order (SURVEY.md 8b "State-dict (strict)"). shape has up to 4 entries. */
+int hcf_param_count(const hcf_engine* e);
+int hcf_param_info(const hcf_engine* e, int index, const char** key, int32_t* ndim, int64_t shape[4]);
+
+/* Replaces nn.Module.load_state_dict(strict=True) as used by BaseModel.load_network
+ * (codes/models/base_model.py:96-120): one call per tensor with a HOST fp32 pointer. */
+int hcf_set_param(hcf_engine* e, const char* key, const float* host_data, const int64_t* shape, int32_t ndim);
+
+/* Pack weights for the kernels (implicit-GEMM layout, ActNorm folded into conv epilogues, W^-1 in
+ * fp64 as Permutations.py:74 does, slogdet hoisted out of the pass) and upload to `device`.
+ * Must be called after the last hcf_set_param and again whenever parameters change. */
+int hcf_finalize(hcf_engine* e, int device);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* netG(lr=lr, z=None, u=None, eps_std=tau, reverse=True): HCFlowNet_SR.reverse_flow_diracLR
+ * (HCFlowNet_SR_arch.py:70-75) and HCFlowNet_Rescaling.reverse_flow_diracLR
+ * (HCFlowNet_Rescaling_arch.py:49-54) -> FlowNet.reverse_flow (FlowNet_SR_x4.py:106-123).
+ *   lr      [B,3,h,w]  device
+ *   eps     n_eps device pointers, sampling order (deepest level first), each [B,C_l,h_l,w_l] and
+ *           ALREADY N(0,tau) distributed (what GaussianDiag.sample draws, Basic.py:98-99); an
+ *           entry (or the whole array) may be NULL -> drawn on device (Philox, `seed`) * tau
+ *   out_hr  [B,3,h*scale,w*scale] device */
+int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
+
+/* netG(hr=hr, lr=lr, reverse=False) for HCFlowNet_SR: normal_flow_diracLR (HCFlowNet_SR_arch.py:47-67).
+ *   hr [B,3,H,W], lr [B,3,H/scale,W/scale] (NULL -> no Dirac term), noise [B,3,H,W] U[0,1) or NULL
+ *   (NULL -> no dequantisation noise is added)
+ *   out_lr [B,3,H/scale,W/scale] = clamp(Quant(z)); out_nll [1]; out_logdet [B] objective per sample
+ *   (nullable); out_z [B,3,H/scale,W/scale] pre-quantisation latent (nullable) */
+int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr, float* out_nll,
+                   float* out_logdet, float* out_z, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
+
+/* netG(hr=hr, reverse=False) for HCFlowNet_Rescaling: normal_flow_diracLR
+ * (HCFlowNet_Rescaling_arch.py:39-46): out_lr = clamp(LR^), out_z1 [B,6,H/2,W/2], out_z2 [B,21,H/4,W/4] */
+int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B, int32_t H,
+                        int32_t W, uint32_t flags, hcf_stream_t stream);
+
+/* bytes of device workspace currently held (activations arena) and of packed weights */
+size_t hcf_workspace_bytes(const hcf_engine* e);
+size_t hcf_weight_bytes(const hcf_engine* e);
+
+/* timing hook used by bench.py: when enabled, every conv launch is bracketed by HIP events on the
+ * launch stream; hcf_conv_time_ms() returns (and clears) the accumulated conv time and count. */
+int hcf_profile_convs(hcf_engine* e, int enable);
+int hcf_conv_time_ms(hcf_engine* e, double* total_ms, int64_t* launches, double* flops);
+
+/* ---- per-op entry points (unit parity tests; tensors are device NCHW fp32) ------------------- */
+/* F.conv2d(x, w, stride 1, padding k/2) with the fused epilogue
+ *   y = res2 + rs2 * (res1 + rs1 * act((conv + bias) * scale))
+ * w is a HOST pointer in PyTorch layout [cout, cin, k, k]; bias/scale HOST [cout] or NULL;
+ * x is the channel-concatenation of n_src device tensors [B, src_c[i], H >> src_up[i], W >> src_up[i]]
+ * (nearest-upsampled by 2^src_up[i]); res1/res2 device [B,cout,H,W] or NULL. k in {1,3}. */
+int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* src_up, int32_t n_src, int32_t B,
+                  int32_t H, int32_t W, const float* w, const float* bias, const float* scale, int32_t cout, int32_t k,
+                  int32_t act, const float* res1, float rs1, const float* res2, float rs2, float* out,
+                  hcf_stream_t stream);
+/* Basic.squeeze2d / unsqueeze2d factor 2 (Basic.py:127-157) and HaarDownsampling (Basic.py:470-487) */
+int hcf_op_squeeze2d(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t haar, hcf_stream_t stream);
+int hcf_op_unsqueeze2d(const float* x, float* out, int32_t B, int32_t C4, int32_t H, int32_t W, int32_t haar, hcf_stream_t stream);
+/* FlowStep.reverse_flow tail / normal_flow head+coupling on given tensors (FlowStep.py:40-64):
+ *   inverse: out = actnorm^-1( Winv @ coupling^-1(z, h) );  forward: zmid = W @ actnorm(z) then
+ *   out = coupling(zmid, h), logdet[b] = sum logscale.  mat: HOST [C,C] (W for forward; the entry
+ *   inverts it in fp64 for inverse) or NULL; bias/logs HOST [C]; mode/ns as hcf_common.h StepArgs. */
+int hcf_op_step_inverse(const float* z, const float* h, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                        int32_t hC, int32_t mode, int32_t ns, const float* mat, const float* an_bias,
+                        const float* an_logs, hcf_stream_t stream);
+int hcf_op_step_forward_head(const float* z, float* out, int32_t B, int32_t C, int32_t H, int32_t W, const float* mat,
+                             const float* an_bias, const float* an_logs, hcf_stream_t stream);
+int hcf_op_step_forward_couple(const float* z, const float* h, float* out, float* logdet, int32_t B, int32_t C,
+                               int32_t H, int32_t W, int32_t hC, int32_t mode, int32_t ns, hcf_stream_t stream);
+/* GaussianDiag.logp / sample (Basic.py:78-101) with (mean, logs) = h[:,0::2], h[:,1::2] */
+int hcf_op_gauss_logp(const float* h, const float* x, float* out_logp, int32_t B, int32_t C, int32_t H, int32_t W,
+                      hcf_stream_t stream);
+int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t seed, float* out, int32_t B, int32_t C,
+                        int32_t H, int32_t W, int32_t rescale, hcf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HCFLOW_H_ */

@@ -1,0 +1,154 @@
+"""-m gpu: end-to-end parity of the engine (through the drop-in classes and the C ABI) against the
+reference-generated golden fixtures and the CPU oracle, plus size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcflow_oracle as O
+from hcflow_amd.config import preset, eps_shapes
+from tests.util import load_golden, params_for, t, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full"]
+NETS_RS = ["net_rescale_tiny", "net_rescale_full"]
+_cache = {}
+
+
+def build_net(cfg, p):
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    key = id(p)
+    if key in _cache:
+        return _cache[key]
+    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval()
+    _cache.clear()
+    _cache[key] = net
+    return net
+
+
+def _eps(g, pre):
+    out, i = [], 0
+    while "%s_eps%d" % (pre, i) in g.files:
+        out.append(t(g["%s_eps%d" % (pre, i)]))
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("name", NETS_SR + NETS_RS)
+def test_inverse_matches_reference(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    net = build_net(cfg, p)
+    with torch.no_grad():
+        for ti in (0, 1):
+            tau = float(g["inv%d_tau" % ti])
+            eps = _eps(g, "inv%d" % ti)
+            raw = net.reverse_flow_diracLR(t(g["lr"]).cuda(), None, None, eps_std=tau, eps=eps, clamp=False)
+            scale = max(1.0, float(np.abs(g["inv%d_raw" % ti]).max()))
+            assert maxdiff(raw, g["inv%d_raw" % ti]) <= 1e-4 * scale, (name, ti, maxdiff(raw, g["inv%d_raw" % ti]))
+            out = net(lr=t(g["lr"]).cuda(), z=None, u=None, eps_std=tau, reverse=True, eps=eps)
+            assert maxdiff(out, g["inv%d_out" % ti]) <= 1e-4
+            assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+
+
+@pytest.mark.parametrize("name", NETS_SR)
+def test_sr_forward_nll_matches_reference(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    net = build_net(cfg, p)
+    with torch.no_grad():
+        hr, lr, noise = t(g["hr"]).cuda(), t(g["lr"]).cuda(), t(g["fwd_noise"]).cuda()
+        lr_hat, nll, logdet, z = net.normal_flow_diracLR(hr, lr, noise=noise, return_internals=True)
+        assert maxdiff(z, g["fwd_z"]) <= 1e-4
+        d = (lr_hat.cpu() - t(g["fwd_lr"])).abs()
+        assert float(d.max()) <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 0.01
+        # self-consistent NLL (lr := LR^): bits/dim within 1e-4 of the reference (BASELINE.json)
+        _, nll_self = net(hr=hr, lr=t(g["fwd_lr"]).cuda(), reverse=False, noise=noise)
+        assert abs(float(nll_self) - float(g["fwd_nll_self"])) <= 1e-4, (float(nll_self), float(g["fwd_nll_self"]))
+        assert abs(float(nll) - float(g["fwd_nll"])) <= 1e-5 * abs(float(g["fwd_nll"]))
+
+
+@pytest.mark.parametrize("name", NETS_RS)
+def test_rescale_forward_and_roundtrip(name):
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    net = build_net(cfg, p)
+    with torch.no_grad():
+        lr_hat, z1, z2 = net(hr=t(g["hr"]).cuda(), reverse=False)
+        assert maxdiff(lr_hat, g["fwd_lr"]) <= 1e-4
+        assert maxdiff(z1, g["fwd_z1"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z1"]).max()))
+        assert maxdiff(z2, g["fwd_z2"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z2"]).max()))
+        rt = net(lr=t(g["rt_lrq"]).cuda(), eps_std=1.0, reverse=True, eps=_eps(g, "rt"))
+        assert maxdiff(rt, g["rt_out"]) <= 1e-4
+
+
+def test_oracle_parity_on_fresh_inputs():
+    """HIP path vs oracle on new seeded inputs (not in the fixtures), ragged LR size, B=3."""
+    cfg = preset("SR_4X_tiny")
+    from tests.util import cached_params
+    p = cached_params("SR_4X_tiny", 11)
+    net = build_net(cfg, p)
+    g = torch.Generator().manual_seed(99)
+    lr = torch.rand(3, 3, 9, 35, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.8 for s in eps_shapes(cfg, 3, 9, 35)]
+    with torch.no_grad():
+        ref = O.sr_inverse(lr, p, cfg, 0.8, eps, clamp=False)
+        out = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.8, eps=eps, clamp=False)
+    assert maxdiff(out, ref) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_rescale_encode_decode_roundtrip_property():
+    """Size-independent property: forward (no clamp) -> inverse with eps := encoded latents
+    reproduces the HR input (invertibility of the whole flow incl. the conditional prior)."""
+    cfg = preset("Rescaling_4X_tiny")
+    from tests.util import cached_params
+    p = cached_params("Rescaling_4X_tiny", 13)
+    net = build_net(cfg, p)
+    g = torch.Generator().manual_seed(5)
+    hr = torch.rand(2, 3, 96, 128, generator=g).cuda()
+    with torch.no_grad():
+        lr_raw, z1, z2 = net.normal_flow_diracLR(hr, clamp=False)
+        back = net.reverse_flow_diracLR(lr_raw, None, None, eps_std=1.0, eps=[z2, z1], clamp=False)
+    assert maxdiff(back, hr) <= 2e-4
+
+
+def test_batch_independence_and_determinism():
+    """Every op is per-sample: sample i of a batched call equals the B=1 call;
+    tau=0 is deterministic; device-sampled eps follows torch.manual_seed."""
+    cfg = preset("SR_4X_tiny")
+    from tests.util import cached_params
+    p = cached_params("SR_4X_tiny", 11)
+    net = build_net(cfg, p)
+    lr = torch.rand(4, 3, 16, 24, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        full = net(lr=lr, eps_std=0.0, reverse=True)
+        for i in (0, 3):
+            one = net(lr=lr[i:i + 1], eps_std=0.0, reverse=True)
+            assert torch.equal(one[0], full[i])
+        assert torch.equal(full, net(lr=lr, eps_std=0.0, reverse=True))
+        torch.manual_seed(7)
+        a = net(lr=lr, eps_std=0.8, reverse=True)
+        torch.manual_seed(7)
+        b = net(lr=lr, eps_std=0.8, reverse=True)
+        c = net(lr=lr, eps_std=0.8, reverse=True)
+        assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_parameter_update_triggers_repack():
+    cfg = preset("SR_4X_tiny")
+    from tests.util import cached_params
+    p = cached_params("SR_4X_tiny", 11)
+    net = build_net(cfg, p)
+    lr = torch.rand(1, 3, 8, 8, generator=torch.Generator().manual_seed(4)).cuda()
+    with torch.no_grad():
+        a = net(lr=lr, eps_std=0.0, reverse=True)
+        net.flow.level0_condFlow.f.bias.add_(0.05)
+        b = net(lr=lr, eps_std=0.0, reverse=True)
+        net.flow.level0_condFlow.f.bias.sub_(0.05)
+        c = net(lr=lr, eps_std=0.0, reverse=True)
+    assert not torch.equal(a, b) and maxdiff(a, c) <= 1e-6
