@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- HR images/s of HCFlow inverse sampling on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): General-SR x4 net
+(test_SR_DF2K_4X_HCFlow.yml network_G: K=26, L=2, after_flowstep [13,13], RRDB_nb [7,7], nf 64,
+gc 32, FCN hidden 64, quant 64), batch 16 per GPU of 160x160 LR patches -> 640x640 HR, tau = 0.8,
+eps drawn on device (Philox), synthetic LR ~ U[0,1) and seeded random weights (no network for
+datasets / checkpoints). One "step" = one netG(lr=..., eps_std=0.8, reverse=True) over the batch,
+followed for N > 1 by the RCCL all-gather of the output batch (north_star). Inputs are resident in
+HBM before the timed region. N > 1 is launched by torch.distributed.run, one rank per GPU, each
+rank samples its own shard (weak scaling, no data-path collective besides the output gather).
+
+The JSON line also carries
+  roofline      dominant kernel = conv_mfma_kernel<3x3, 64 out-ch>: fp32 MFMA bound; achieved =
+                algorithmic conv FLOPs / kernel time measured with HIP events on the launch stream
+                inside the timed region; peak 157.3 TFLOP/s (MI355X_MICROARCH.md, fp32 matrix)
+  cpu_baseline  the CPU oracle (oracle/hcflow_oracle.py, a PyTorch-CPU port of the reference
+                path) timed on this host on a bounded sample (B=1 patches), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                 # HBM3E spec
+GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
+IDEAL_GB_PER_IMAGE = 23.02            # layer-wise-ideal fp32 HBM traffic per image
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="LR patches per GPU per step")
+    ap.add_argument("--lr-size", type=int, default=160)
+    ap.add_argument("--tau", type=float, default=0.8)
+    ap.add_argument("--preset", default="SR_DF2K_4X")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling, preset, make_params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = preset(args.preset)
+    params = make_params(cfg, 1234)
+    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(params, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True                      # what HCFlow_SR_model.load() does (:448)
+    net = net.to(dev).eval()
+
+    B, h = args.batch, args.lr_size
+    g = torch.Generator().manual_seed(1000 + rank)
+    lr = torch.rand(B, 3, h, h, generator=g).to(dev)
+    out_all = torch.empty(world * B, 3, h * cfg.scale, h * cfg.scale, device=dev) if world > 1 else None
+    torch.manual_seed(rank)
+
+    def step():
+        out = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+        if world > 1:
+            dist.all_gather_into_tensor(out_all, out)     # RCCL over xGMI: output batch only
+        return out
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        eng = net.engine()
+        eng.profile_convs(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.profile_convs(False)
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        img_s = world * B * args.steps / dt
+        # dominant kernel: 3x3 conv with 2 N-tiles (64 output channels): RRDB conv5 / FCN conv1
+        ms, n, fl = eng.conv_time(9, 2, reset=False)
+        ms_all, n_all, fl_all = eng.conv_time(0, 0, reset=True)
+        achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "kernel": "conv_mfma_kernel<9,2> (3x3, 64 out-ch, fp32 MFMA 32x32x2)",
+            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+            "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+            "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / args.steps, 3),
+                          "tflops": round((fl_all / 1e12) / (ms_all / 1e3), 3) if ms_all > 0 else 0.0,
+                          "frac_of_step_time": round(ms_all / 1e3 / dt, 4)},
+        }
+        if args.preset == "SR_DF2K_4X" and h == 160:
+            per_gpu = img_s / world
+            roofline["whole_pass"] = {
+                "mfma_frac": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                "hbm_frac_layerwise_ideal": round(per_gpu * IDEAL_GB_PER_IMAGE / PEAK_HBM_GBS, 4)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, params, h, args.tau, args.cpu_passes)
+        line = {
+            "metric": "HR images/sec (inverse sample) DIV2K x4 160px LR", "value": round(img_s, 4),
+            "unit": "HR images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s inverse sampling (netG reverse=True), batch %d/GPU, LR %dx%d -> HR %dx%d, "
+                                   "tau=%.1f, eps on device, output all-gather over RCCL for N>1"
+                                   % (args.preset, B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
+                       "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
+                       "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
+                       "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, params, h, tau, passes):
+    """Oracle (PyTorch-CPU port of the reference path) on this host: B=1 patches of the same
+    workload, same weights. The oracle is only the thing MEASURED AGAINST, never the product."""
+    import torch
+    from oracle import hcflow_oracle as O
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+    lr = torch.rand(1, 3, h, h, generator=g)
+    fn = O.sr_inverse if cfg.sr else O.rescale_inverse
+    with torch.no_grad():
+        fn(lr, params, cfg, tau)                         # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            fn(lr, params, cfg, tau)
+        dt = time.perf_counter() - t0
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(passes / dt, 4), "unit": "HR images/s", "cores": threads, "kind": "port",
+            "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN) %d timed passes of B=1 LR %dx%d tau=%.1f "
+                      "after 1 warm-up; %.1f s" % (passes, h, h, tau, dt),
+            "cpu": cpu_model, "s_per_image": round(dt / passes, 3)}
+
+
+if __name__ == "__main__":
+    main()

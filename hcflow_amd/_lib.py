@@ -73,7 +73,7 @@ def load() -> C.CDLL:
     lib.hcf_weight_bytes.argtypes = [vp]
     lib.hcf_weight_bytes.restype = C.c_size_t
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
-    lib.hcf_conv_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
                                   i32, i32, i32, fp, f32, fp, f32, fp, vp]
     lib.hcf_op_squeeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
@@ -167,6 +167,16 @@ class Engine:
 
     def finalize(self, device: int):
         check(self.lib.hcf_finalize(self._h, int(device)), self._h, "hcf_finalize")
+
+    def profile_convs(self, enable: bool):
+        check(self.lib.hcf_profile_convs(self._h, int(enable)), self._h, "hcf_profile_convs")
+
+    def conv_time(self, taps: int = 0, nt: int = 0, reset: bool = False):
+        """(total_ms, launches, algorithmic_flops) of the recorded conv launches of one variant."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        check(self.lib.hcf_conv_time_ms(self._h, taps, nt, int(reset), C.byref(ms), C.byref(n), C.byref(fl)),
+              self._h, "hcf_conv_time_ms")
+        return ms.value, n.value, fl.value
 
     def workspace_bytes(self) -> int:
         return int(self.lib.hcf_workspace_bytes(self._h))

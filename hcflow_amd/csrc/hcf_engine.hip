@@ -126,9 +126,9 @@ struct hcf_engine {
   std::string err;
   // conv profiling
   bool prof = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  struct ProfRec { hipEvent_t e0, e1; int taps, nt; double flops; };
+  std::vector<ProfRec> prof_events;
   size_t prof_used = 0;
-  double prof_flops = 0;
   // build state
   bool spec_mode = true;
   int rc = HCF_OK;
@@ -480,18 +480,20 @@ struct hcf_engine {
     if (dry()) return;
     if (prof) {
       if (prof_used == prof_events.size()) {
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        prof_events.push_back({e0, e1});
+        ProfRec r;
+        hipEventCreate(&r.e0);
+        hipEventCreate(&r.e1);
+        prof_events.push_back(r);
       }
-      hipEventRecord(prof_events[prof_used].first, st);
+      prof_events[prof_used].taps = cv.taps;
+      prof_events[prof_used].nt = cv.npad / 32;
+      prof_events[prof_used].flops = cv.flops_per_pixel * (double)B_ * H * W;
+      hipEventRecord(prof_events[prof_used].e0, st);
     }
     const int r = launch_conv(a, cv.taps, st);
     if (prof) {
-      hipEventRecord(prof_events[prof_used].second, st);
+      hipEventRecord(prof_events[prof_used].e1, st);
       prof_used++;
-      prof_flops += cv.flops_per_pixel * (double)B_ * H * W;
     }
     if (r != HCF_OK) fail(r, "conv launch failed");
   }
@@ -861,7 +863,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->device >= 0) hipSetDevice(e->device);
   e->free_weights();
   if (e->arena.base) hipFree(e->arena.base);
-  for (auto& pr : e->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
 
@@ -951,24 +953,28 @@ int hcf_profile_convs(hcf_engine* e, int enable) {
   if (!e) return HCF_ERR_ARG;
   e->prof = enable != 0;
   e->prof_used = 0;
-  e->prof_flops = 0;
   return HCF_OK;
 }
 
-int hcf_conv_time_ms(hcf_engine* e, double* total_ms, int64_t* launches, double* flops) {
+int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t reset, double* total_ms, int64_t* launches,
+                     double* flops) {
   if (!e) return HCF_ERR_ARG;
-  double tot = 0;
+  double tot = 0, fl = 0;
+  int64_t n = 0;
   for (size_t i = 0; i < e->prof_used; ++i) {
-    if (hipEventSynchronize(e->prof_events[i].second) != hipSuccess) return HCF_ERR_HIP;
+    const auto& r = e->prof_events[i];
+    if ((taps && r.taps != taps) || (nt && r.nt != nt)) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return HCF_ERR_HIP;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second) != hipSuccess) return HCF_ERR_HIP;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return HCF_ERR_HIP;
     tot += ms;
+    fl += r.flops;
+    n++;
   }
   if (total_ms) *total_ms = tot;
-  if (launches) *launches = (int64_t)e->prof_used;
-  if (flops) *flops = e->prof_flops;
-  e->prof_used = 0;
-  e->prof_flops = 0;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  if (reset) e->prof_used = 0;
   return HCF_OK;
 }
 
