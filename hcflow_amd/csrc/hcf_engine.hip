@@ -951,8 +951,8 @@ size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }
 
 int hcf_profile_convs(hcf_engine* e, int enable) {
   if (!e) return HCF_ERR_ARG;
+  if (enable && !e->prof) e->prof_used = 0;     // records survive a disable so they can be read afterwards
   e->prof = enable != 0;
-  e->prof_used = 0;
   return HCF_OK;
 }
 
