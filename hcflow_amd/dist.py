@@ -1,0 +1,76 @@
+"""Batch-sharded multi-GPU sampling: one process per GPU, RCCL all-gather of the output batch only.
+
+New functionality relative to the reference (its test loader is hard-wired to batch 1,
+codes/data/__init__.py:24; only DDP training uses NCCL): every op of the path is per-sample
+(SURVEY.md section 8e), so a batch is split into contiguous shards, each rank runs the whole net on
+its shard with its own engine, and ONE ``all_gather_into_tensor`` assembles the result. With
+``torch.distributed`` backend "nccl" this is RCCL over xGMI on MI355X; the same code runs over
+"gloo" on CPU tensors (tests/test_dist_cpu.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(B: int, world: int, rank: int):
+    """Contiguous, balanced shards: the first B % world ranks get one extra sample."""
+    base, extra = divmod(B, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, group=None,
+                  extras: Optional[Sequence[Optional[torch.Tensor]]] = None) -> torch.Tensor:
+    """Run ``fn`` on this rank's batch shard of ``x`` (and of each tensor in ``extras``) and
+    all-gather the outputs along dim 0. Every rank passes the same full ``x`` and gets the same full result."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return fn(x) if extras is None else fn(x, *extras)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = x.shape[0]
+    lo, hi = shard_bounds(B, world, rank)
+    n_max = -(-B // world)
+    if hi > lo:
+        args = [x[lo:hi]]
+        if extras is not None:
+            args += [None if e is None else e[lo:hi] for e in extras]
+        y = fn(*args)
+    else:                                     # more ranks than samples: run one sample to learn the shape
+        args = [x[:1]]
+        if extras is not None:
+            args += [None if e is None else e[:1] for e in extras]
+        y = fn(*args)[:0]
+    pad = torch.zeros((n_max,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+    pad[: y.shape[0]] = y
+    out = torch.empty((world * n_max,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)      # the only collective of the path
+    if B == world * n_max:
+        return out
+    pieces = []
+    for r in range(world):
+        l, h = shard_bounds(B, world, r)
+        pieces.append(out[r * n_max: r * n_max + (h - l)])
+    return torch.cat(pieces, 0)
+
+
+def sharded_inverse(net, lr: torch.Tensor, eps_std: float, eps: Optional[Sequence[torch.Tensor]] = None, group=None):
+    """netG(lr=..., eps_std=..., reverse=True) over a batch sharded across the ranks of ``group``.
+
+    ``eps`` (optional, parity runs): full-batch N(0, tau) tensors in sampling order; each rank uses its slice.
+    """
+    if eps is None:
+        return sharded_apply(lambda s: net(lr=s, z=None, u=None, eps_std=eps_std, reverse=True), lr, group)
+    return sharded_apply(lambda s, *e: net(lr=s, z=None, u=None, eps_std=eps_std, reverse=True, eps=list(e)),
+                         lr, group, extras=list(eps))
+
+
+def sharded_rescale_roundtrip(net, hr: torch.Tensor, eps_std: float = 1.0, group=None):
+    """Config 4 of BASELINE.json: forward -> Quant -> inverse per shard (HCFlow_Rescaling_model.py:306-324),
+    all-gather of the reconstructed HR only (LR^ stays local)."""
+    def fn(s):
+        lr_hat, _, _ = net(hr=s, reverse=False)
+        lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.      # Basic.Quant.forward (Basic.py:187-191)
+        return net(lr=lrq, z=None, u=None, eps_std=eps_std, reverse=True)
+    return sharded_apply(fn, hr, group)
