@@ -23,7 +23,8 @@ SYMBOLS = [
     "hcf_workspace_bytes", "hcf_weight_bytes", "hcf_profile_convs", "hcf_conv_time_ms",
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
-    "hcf_op_gauss_sample",
+    "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
+    "hcf_op_set_precision",
 ]
 
 
@@ -72,6 +73,13 @@ def load() -> C.CDLL:
     lib.hcf_workspace_bytes.restype = C.c_size_t
     lib.hcf_weight_bytes.argtypes = [vp]
     lib.hcf_weight_bytes.restype = C.c_size_t
+    lib.hcf_set_precision.argtypes = [vp, i32]
+    lib.hcf_get_precision.argtypes = [vp]
+    lib.hcf_fallback_count.argtypes = [vp]
+    lib.hcf_fallback_count.restype = C.c_int64
+    lib.hcf_op_set_precision.argtypes = [i32]
+    lib.hcf_bench_conv.argtypes = [i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), vp]
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
     lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
@@ -85,7 +93,8 @@ def load() -> C.CDLL:
     lib.hcf_op_gauss_sample.argtypes = [fp, fp, f32, u64, fp, i32, i32, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("hcf_destroy", "hcf_last_error", "hcf_workspace_bytes", "hcf_weight_bytes"):
+        if name not in ("hcf_destroy", "hcf_last_error", "hcf_workspace_bytes", "hcf_weight_bytes",
+                        "hcf_fallback_count"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -167,6 +176,14 @@ class Engine:
 
     def finalize(self, device: int):
         check(self.lib.hcf_finalize(self._h, int(device)), self._h, "hcf_finalize")
+
+    PRECISIONS = {"exact": 0, "f16x3": 1}
+
+    def set_precision(self, mode: str):
+        check(self.lib.hcf_set_precision(self._h, self.PRECISIONS[mode]), self._h, "hcf_set_precision")
+
+    def fallback_count(self) -> int:
+        return int(self.lib.hcf_fallback_count(self._h))
 
     def profile_convs(self, enable: bool):
         check(self.lib.hcf_profile_convs(self._h, int(enable)), self._h, "hcf_profile_convs")

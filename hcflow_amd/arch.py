@@ -242,6 +242,16 @@ class _EngineModule(nn.Module):
         assert have == spec, "internal: module tree does not match the reference state_dict table"
         # engines are per device (nn.DataParallel replicas share this dict but not the entries)
         object.__setattr__(self, "_engines", {})
+        object.__setattr__(self, "_precision", ["exact"])
+
+    def set_precision(self, mode: str):
+        """"exact": fp32 MFMA convolutions (default). "f16x3": fp32-equivalent split products on the
+        f16 matrix cores with fp32 accumulation (include/hcflow.h: hcf_set_precision)."""
+        assert mode in _lib.Engine.PRECISIONS, mode
+        self._precision[0] = mode
+        for ent in self._engines.values():
+            ent["engine"].set_precision(mode)
+        return self
 
     # -- engine management
     def _engine_for(self, device: torch.device):
@@ -253,6 +263,7 @@ class _EngineModule(nn.Module):
         ent = self._engines.get(idx)
         if ent is None:
             ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
+            ent["engine"].set_precision(self._precision[0])
             self._engines[idx] = ent
         stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if ent["stamp"] != stamp:

@@ -50,11 +50,15 @@ struct ConvArgs {
   View out;                // n = cout
   View res1; float rs1;    // res1.p == nullptr -> skipped
   View res2; float rs2;
+  int* ovf;                // f16x3 kernel only: device flag raised when an input exceeds the f16 range
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
+// fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
+int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
 
 // ---- flow-step glue --------------------------------------------------------------------------
 enum { CPL_AFFINE = 0, CPL_SHIFT3 = 1 };

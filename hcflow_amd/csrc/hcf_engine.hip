@@ -39,6 +39,7 @@ struct Spec {
 struct Conv {
   int taps = 9, cout = 0, nsrc = 0, src_n[kMaxSrc] = {0, 0, 0}, nchunk = 0, npad = 0, act = ACT_NONE;
   float *wpack = nullptr, *bias = nullptr, *scale = nullptr;   // device
+  float* wpack16 = nullptr;                                     // device, f16x3 split pack (or null: exact only)
   double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
 };
 
@@ -109,6 +110,44 @@ void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* s
           }
 }
 
+// f16x3 pack for hcf_conv_f16x3.hip: halves [chunk][tap][which(3)][npad][16] with
+// which = { f16(w) * 2^11, f16((w - f16(w)) * 2^11), f16(w) }, plus one zero (chunk,tap) step for the
+// prefetch. Returns false when a weight is too large for the scaled hi plane (|w| * 2^11 >= 65504).
+bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc,
+                             std::vector<float>& pk_as_float, int& nchunk, int& npad) {
+  int kv = 0;
+  for (int i = 0; i < nsrc; ++i) kv += ru4(srcs[i]);
+  nchunk = (kv + 15) / 16;
+  npad = ((cout + 31) / 32) * 32;
+  std::vector<int> vmap((size_t)nchunk * 16, -1);
+  int v = 0, real = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    for (int c = 0; c < srcs[i]; ++c) vmap[v + c] = real + c;
+    v += ru4(srcs[i]);
+    real += srcs[i];
+  }
+  const size_t plane = (size_t)npad * 16, step = 3 * plane;
+  std::vector<_Float16> pk(((size_t)nchunk * taps + 1) * step, (_Float16)0.f);
+  for (int ch = 0; ch < nchunk; ++ch)
+    for (int t = 0; t < taps; ++t)
+      for (int n = 0; n < cout; ++n)
+        for (int e = 0; e < 16; ++e) {
+          const int ci = vmap[ch * 16 + e];
+          if (ci < 0) continue;
+          const float x = w[((size_t)n * cin + ci) * taps + t];
+          if (!(fabsf(x) * 2048.f < 60000.f)) return false;
+          const _Float16 hi = (_Float16)x;
+          const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
+          const size_t o = ((size_t)ch * taps + t) * step + (size_t)n * 16 + e;
+          pk[o] = (_Float16)((float)hi * 2048.f);
+          pk[o + plane] = lo;
+          pk[o + 2 * plane] = hi;
+        }
+  pk_as_float.assign((pk.size() + 1) / 2, 0.f);
+  memcpy(pk_as_float.data(), pk.data(), pk.size() * sizeof(_Float16));
+  return true;
+}
+
 }  // namespace hcf
 
 using namespace hcf;
@@ -132,6 +171,11 @@ struct hcf_engine {
   // build state
   bool spec_mode = true;
   int rc = HCF_OK;
+  // numerics: PREC_EXACT = fp32 MFMA everywhere; PREC_F16X3 = fp32-equivalent split on f16 MFMA
+  int precision = PREC_EXACT;
+  bool use_f16 = false;        // precision of the pass being enqueued
+  int* ovf_flag = nullptr;     // device
+  int64_t n_fallbacks = 0;
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -218,6 +262,12 @@ struct hcf_engine {
     cv.wpack = upload(pk);
     cv.bias = upload(b);
     cv.scale = upload(s);
+    cv.wpack16 = nullptr;
+    if (cv.npad <= 64) {
+      std::vector<float> pk16;
+      int nc = 0, np = 0;
+      if (pack_conv_weights_f16x3(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk16, nc, np)) cv.wpack16 = upload(pk16);
+    }
   }
 
   // nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
@@ -490,7 +540,14 @@ struct hcf_engine {
       prof_events[prof_used].flops = cv.flops_per_pixel * (double)B_ * H * W;
       hipEventRecord(prof_events[prof_used].e0, st);
     }
-    const int r = launch_conv(a, cv.taps, st);
+    int r;
+    if (use_f16 && cv.wpack16) {
+      a.wpack = cv.wpack16;
+      a.ovf = ovf_flag;
+      r = launch_conv_f16x3(a, cv.taps, st);
+    } else {
+      r = launch_conv(a, cv.taps, st);
+    }
     if (prof) {
       hipEventRecord(prof_events[prof_used].e1, st);
       prof_used++;
@@ -809,7 +866,8 @@ struct hcf_engine {
   }
 
   template <class F>
-  int run_pass(F&& body, hipStream_t stream) {
+  int run_pass(F&& body, hipStream_t stream, uint32_t flags = 0) {
+    pass_flags = flags;
     if (!finalized) return fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
@@ -820,9 +878,29 @@ struct hcf_engine {
     arena.dry = false;
     if (rc != HCF_OK) return rc;
     if (ensure_arena(arena.peak) != HCF_OK) return rc;
+    use_f16 = (precision == PREC_F16X3);
+    if (use_f16) {
+      if (!ovf_flag && hipMalloc((void**)&ovf_flag, sizeof(int)) != hipSuccess)
+        return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
+      if (hipMemsetAsync(ovf_flag, 0, sizeof(int), st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+    }
     body();
+    if (use_f16 && rc == HCF_OK && !(pass_flags & HCF_FLAG_NO_RANGE_CHECK)) {
+      // an activation beyond the f16 range (|x| >= 65504) cannot be split: redo the pass exactly
+      int h = 0;
+      if (hipMemcpyAsync(&h, ovf_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        return fail(HCF_ERR_HIP, "reading the overflow flag failed");
+      if (h) {
+        n_fallbacks++;
+        use_f16 = false;
+        body();
+      }
+    }
+    use_f16 = false;
     return rc;
   }
+  uint32_t pass_flags = 0;
 };
 
 // ================================================================================================
@@ -863,6 +941,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->device >= 0) hipSetDevice(e->device);
   e->free_weights();
   if (e->arena.base) hipFree(e->arena.base);
+  if (e->ovf_flag) hipFree(e->ovf_flag);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
@@ -923,7 +1002,8 @@ int hcf_finalize(hcf_engine* e, int device) {
 int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
                 float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream) {
   if (!e || !lr || !out_hr || B < 1 || h < 1 || w < 1) return HCF_ERR_ARG;
-  return e->run_pass([&]() { e->pass_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags); }, (hipStream_t)stream);
+  return e->run_pass([&]() { e->pass_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags); }, (hipStream_t)stream,
+                     flags);
 }
 
 int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr, float* out_nll,
@@ -945,6 +1025,16 @@ int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* ou
   return e->run_pass([&]() { e->pass_forward(hr, nullptr, nullptr, out_lr, nullptr, nullptr, nullptr, out_z1, out_z2, B, H, W, flags); },
                      (hipStream_t)stream);
 }
+
+int hcf_set_precision(hcf_engine* e, int32_t mode) {
+  if (!e || (mode != PREC_EXACT && mode != PREC_F16X3)) return HCF_ERR_ARG;
+  e->precision = mode;
+  return HCF_OK;
+}
+
+int hcf_get_precision(const hcf_engine* e) { return e ? e->precision : HCF_ERR_ARG; }
+
+int64_t hcf_fallback_count(const hcf_engine* e) { return e ? e->n_fallbacks : -1; }
 
 size_t hcf_workspace_bytes(const hcf_engine* e) { return e ? e->arena.cap : 0; }
 size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }

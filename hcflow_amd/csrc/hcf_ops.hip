@@ -12,6 +12,9 @@
 namespace hcf {
 void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc, std::vector<float>& pk,
                        int& nchunk, int& npad);
+bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc,
+                             std::vector<float>& pk_as_float, int& nchunk, int& npad);
+static int g_op_precision = PREC_EXACT;
 
 static inline int ru4(int c) { return (c + 3) & ~3; }
 
@@ -33,6 +36,28 @@ struct Tmp {
     for (void* p : ptrs) hipFree(p);
   }
 };
+
+// pack + launch with the process-wide op precision; returns HCF_ERR_* (f16x3: also checks the range flag)
+static int pack_and_launch(Tmp& t, ConvArgs& a, const float* w, int cin, int cout, int k, const int* srcs, int n_src,
+                           hipStream_t st, int iters = 1) {
+  std::vector<float> pk;
+  int nchunk = 0, npad = 0;
+  const bool f16 = (g_op_precision == PREC_F16X3) && cout <= 64;
+  if (f16) {
+    if (!pack_conv_weights_f16x3(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad)) return HCF_ERR_UNSUPPORTED;
+    a.ovf = (int*)t.dev(1);
+    if (a.ovf && hipMemsetAsync(a.ovf, 0, sizeof(int), st) != hipSuccess) return HCF_ERR_HIP;
+  } else {
+    pack_conv_weights(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad);
+  }
+  a.wpack = t.up(pk);
+  a.nchunk = nchunk;
+  if (!t.ok) return HCF_ERR_NOMEM;
+  int rc = HCF_OK;
+  for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
+  return rc;
+}
+
 
 static View nhwc_from_nchw(Tmp& t, const float* x, int B, int C, int H, int W, hipStream_t st, int& rc) {
   float* p = t.dev((size_t)B * H * W * ru4(C));
@@ -106,18 +131,14 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
   for (int i = n_src; i < kMaxSrc; ++i) a.src[i] = a.src[0];
   a.nsrc = n_src;
   a.B = B; a.H = H; a.W = W;
-  std::vector<float> pk;
-  int nchunk = 0, npad = 0;
-  pack_conv_weights(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad);
+  const int npad = ((cout + 31) / 32) * 32;
   std::vector<float> hb(npad, 0.f), hs(npad, 1.f);
   for (int n = 0; n < cout; ++n) {
     if (bias) hb[n] = bias[n];
     if (scale) hs[n] = scale[n];
   }
-  a.wpack = t.up(pk);
   a.bias = t.up(hb);
   a.scale = t.up(hs);
-  a.nchunk = nchunk;
   a.act = act;
   float* o = t.dev((size_t)B * H * W * ru4(cout));
   a.out = mkview(o, ru4(cout), 0, cout);
@@ -127,11 +148,22 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
   if (res2) { a.res2 = nhwc_from_nchw(t, res2, B, cout, H, W, st, rc); a.rs2 = rs2; }
   if (!t.ok) return HCF_ERR_NOMEM;
   if (rc != HCF_OK) return rc;
-  rc = launch_conv(a, k * k, st);
+  rc = pack_and_launch(t, a, w, cin, cout, k, srcs, n_src, st);
   if (rc != HCF_OK) return rc;
   rc = launch_nhwc_to_nchw(a.out, out, B, cout, H, W, 0, st);
   if (hipStreamSynchronize(st) != hipSuccess) return HCF_ERR_HIP;
+  if (a.ovf) {
+    int h = 0;
+    if (hipMemcpy(&h, a.ovf, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return HCF_ERR_HIP;
+    if (h) return HCF_ERR_UNSUPPORTED;      // input beyond the f16 range: caller must use the exact kernel
+  }
   return rc;
+}
+
+int hcf_op_set_precision(int32_t mode) {
+  if (mode != PREC_EXACT && mode != PREC_F16X3) return HCF_ERR_ARG;
+  g_op_precision = mode;
+  return HCF_OK;
 }
 
 int hcf_op_squeeze2d(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t haar,
@@ -298,3 +330,58 @@ int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t se
 }
 
 }  // extern "C"
+
+// ---- micro-benchmark of the conv kernel (tools/conv_bench.py) ---------------------------------
+// Allocates NHWC slabs once, launches the conv `iters` times back to back and times them with HIP
+// events on the given stream. Inputs are uniform random in [-1, 1) (never zeros: DVFS, cdna guide
+// rule 25); weights random. ms = average per launch.
+extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* src_c, int32_t n_src, int32_t cout,
+                              int32_t k, int32_t iters, double* ms_per_launch, double* flops_per_launch,
+                              hcf_stream_t stream) {
+  if (!src_c || n_src < 1 || n_src > kMaxSrc || iters < 1) return HCF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Tmp t;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  int cin = 0, srcs[kMaxSrc];
+  uint32_t rng = 12345u;
+  auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) * (1.0f / 8388608.0f)) - 1.0f; };
+  for (int i = 0; i < n_src; ++i) {
+    const int cs = ru4(src_c[i]);
+    const size_t n = (size_t)B * H * W * cs;
+    std::vector<float> h(n);
+    for (size_t j = 0; j < n; ++j) h[j] = rnd();
+    a.src[i] = mkview(t.up(h), cs, 0, src_c[i]);
+    srcs[i] = src_c[i];
+    cin += src_c[i];
+  }
+  for (int i = n_src; i < kMaxSrc; ++i) a.src[i] = a.src[0];
+  a.nsrc = n_src;
+  a.B = B; a.H = H; a.W = W;
+  std::vector<float> w((size_t)cout * cin * k * k);
+  for (auto& v : w) v = rnd() * 0.05f;
+  const int npad = ((cout + 31) / 32) * 32;
+  std::vector<float> hb(npad, 0.1f), hs(npad, 1.f);
+  a.bias = t.up(hb); a.scale = t.up(hs);
+  a.act = ACT_LRELU;
+  a.out = mkview(t.dev((size_t)B * H * W * ru4(cout)), ru4(cout), 0, cout);
+  a.res1 = mkview(nullptr, 0, 0, 0);
+  a.res2 = mkview(nullptr, 0, 0, 0);
+  if (!t.ok) return HCF_ERR_NOMEM;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  int rc = pack_and_launch(t, a, w.data(), cin, cout, k, srcs, n_src, st);     // pack + warm-up
+  const bool f16 = a.ovf != nullptr;
+  hipEventRecord(e0, st);
+  for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
+  hipEventRecord(e1, st);
+  if (hipEventSynchronize(e1) != hipSuccess) rc = HCF_ERR_HIP;
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (ms_per_launch) *ms_per_launch = ms / iters;
+  if (flops_per_launch) *flops_per_launch = 2.0 * k * k * cin * (double)cout * B * H * W;
+  return rc;
+}

@@ -33,6 +33,11 @@ def _stream(t):
 ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2}
 
 
+def set_precision(mode: str):
+    """Numerics of conv2d() below: "exact" (fp32 MFMA) or "f16x3" (split products on f16 MFMA)."""
+    _lib.check(_lib.load().hcf_op_set_precision(_lib.Engine.PRECISIONS[mode]), None, "hcf_op_set_precision")
+
+
 def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias=None, scale=None, act=None,
            ups: Optional[Sequence[int]] = None, res1=None, rs1=0.0, res2=None, rs2=0.0) -> torch.Tensor:
     """act((conv(cat(upsampled srcs), weight) + bias) * scale) [* rs1 + res1] [* rs2 + res2]."""

@@ -47,7 +47,12 @@ extern "C" {
 #define HCF_NN_DENSEBLOCK 1
 
 /* flags for hcf_inverse / hcf_forward_* */
-#define HCF_FLAG_NO_CLAMP 1u      /* return the flow output before torch.clamp(.,0,1) (parity tests) */
+#define HCF_FLAG_NO_CLAMP 1u        /* return the flow output before torch.clamp(.,0,1) (parity tests) */
+#define HCF_FLAG_NO_RANGE_CHECK 2u  /* f16x3 mode: skip the end-of-pass range check (no stream sync, no exact re-run) */
+
+/* numerics of the convolutions (hcf_set_precision) */
+#define HCF_PRECISION_EXACT 0       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define HCF_PRECISION_F16X3 1       /* fp32-equivalent: 3 f16 MFMAs per product block, fp32 accumulate */
 
 typedef void* hcf_stream_t;        /* a hipStream_t */
 typedef struct hcf_engine hcf_engine;
@@ -116,6 +121,16 @@ int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float*
 int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B, int32_t H,
                         int32_t W, uint32_t flags, hcf_stream_t stream);
 
+/* Convolution numerics. HCF_PRECISION_EXACT (default): fp32 MFMA, an exact fp32 fma chain.
+ * HCF_PRECISION_F16X3: every fp32 product is formed from f16 hi/lo parts (a_hi b_hi + a_hi b_lo +
+ * a_lo b_hi, error ~2^-22) on the 16x faster f16 matrix cores with fp32 accumulation; deviation
+ * from fp64 on the full nets equals plain fp32's. Inputs beyond the f16 range raise
+ * a device flag: the pass is then transparently re-run exactly (one stream sync per pass; see
+ * HCF_FLAG_NO_RANGE_CHECK). hcf_fallback_count = number of passes that were re-run. */
+int hcf_set_precision(hcf_engine* e, int32_t mode);
+int hcf_get_precision(const hcf_engine* e);
+int64_t hcf_fallback_count(const hcf_engine* e);
+
 /* bytes of device workspace currently held (activations arena) and of packed weights */
 size_t hcf_workspace_bytes(const hcf_engine* e);
 size_t hcf_weight_bytes(const hcf_engine* e);
@@ -157,6 +172,12 @@ int hcf_op_gauss_logp(const float* h, const float* x, float* out_logp, int32_t B
                       hcf_stream_t stream);
 int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t seed, float* out, int32_t B, int32_t C,
                         int32_t H, int32_t W, int32_t rescale, hcf_stream_t stream);
+
+/* precision used by the per-op entry points hcf_op_conv2d / hcf_bench_conv (process-wide test knob) */
+int hcf_op_set_precision(int32_t mode);
+/* tools/conv_bench.py: times `iters` back-to-back launches of the conv kernel on random NHWC slabs */
+int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* src_c, int32_t n_src, int32_t cout, int32_t k,
+                   int32_t iters, double* ms_per_launch, double* flops_per_launch, hcf_stream_t stream);
 
 #ifdef __cplusplus
 }

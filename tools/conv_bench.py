@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Micro-benchmark of conv_mfma_kernel on the shapes that dominate config 2 (B=16).
+    python tools/conv_bench.py [--iters 10]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from hcflow_amd import _lib  # noqa: E402
+
+SHAPES = [
+    # name, B, H, W, srcs, cout, k
+    ("rdb_conv5_L0  64+128->64 @320", 16, 320, 320, [64, 128], 64, 3),
+    ("rdb_conv4_L0  64+96->32  @320", 16, 320, 320, [64, 96], 32, 3),
+    ("rdb_conv1_L0  64->32     @320", 16, 320, 320, [64], 32, 3),
+    ("rdb_conv5_L1  64+128->64 @160", 16, 160, 160, [64, 128], 64, 3),
+    ("rdb_conv2_L1  64+32->32  @160", 16, 160, 160, [64, 32], 32, 3),
+    ("fcn_conv1_L0c 3+128->64  @320", 16, 320, 320, [3, 128], 64, 3),
+    ("fcn_conv3_L0c 64->6      @320", 16, 320, 320, [64], 6, 3),
+    ("fcn_conv2     64->64 1x1 @320", 16, 320, 320, [64], 64, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=int, default=-1)
+    args = ap.parse_args()
+    lib = _lib.load()
+    lib.hcf_bench_conv.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+    lib.hcf_bench_conv.restype = C.c_int
+    torch.cuda.init()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i, (name, B, H, W, srcs, cout, k) in enumerate(SHAPES):
+        if args.only >= 0 and i != args.only:
+            continue
+        arr = (C.c_int32 * len(srcs))(*srcs)
+        ms, fl = C.c_double(), C.c_double()
+        rc = lib.hcf_bench_conv(B, H, W, arr, len(srcs), cout, k, args.iters, C.byref(ms), C.byref(fl), st)
+        assert rc == 0, rc
+        print("%-34s %9.1f us  %7.2f TFLOP/s  (%5.1f %% of 157.3)" % (name, ms.value * 1e3, fl.value / ms.value / 1e9,
+                                                                 100 * fl.value / ms.value / 1e9 / 157.3), flush=True)
+
+
+if __name__ == "__main__":
+    main()
