@@ -24,7 +24,7 @@ SYMBOLS = [
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
-    "hcf_op_set_precision",
+    "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
 ]
 
 
@@ -78,6 +78,9 @@ def load() -> C.CDLL:
     lib.hcf_fallback_count.argtypes = [vp]
     lib.hcf_fallback_count.restype = C.c_int64
     lib.hcf_op_set_precision.argtypes = [i32]
+    lib.hcf_debug_set_ablation.argtypes = [i32]
+    lib.hcf_debug_last_clock_mhz.argtypes = []
+    lib.hcf_debug_last_clock_mhz.restype = C.c_double
     lib.hcf_bench_conv.argtypes = [i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp]
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
@@ -94,7 +97,7 @@ def load() -> C.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("hcf_destroy", "hcf_last_error", "hcf_workspace_bytes", "hcf_weight_bytes",
-                        "hcf_fallback_count"):
+                        "hcf_fallback_count", "hcf_debug_last_clock_mhz"):
             fn.restype = C.c_int
     _lib = lib
     return lib

@@ -51,6 +51,8 @@ struct ConvArgs {
   View res1; float rs1;    // res1.p == nullptr -> skipped
   View res2; float rs2;
   int* ovf;                // f16x3 kernel only: device flag raised when an input exceeds the f16 range
+  int any_up;              // set by the launcher: some source window is read through an upsample
+  unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };

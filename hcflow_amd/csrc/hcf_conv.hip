@@ -25,6 +25,10 @@ namespace hcf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space: a pointer rebuilt from SGPR halves would otherwise be "generic" and
+// its loads become flat_load, which also tick lgkmcnt and so serialise with every LDS wait
+typedef const float __attribute__((address_space(1)))* gfptr;
+typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 
 constexpr int KC = 16;   // virtual channels per LDS stage
 constexpr int TH = 8;
@@ -38,11 +42,11 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+__device__ __forceinline__ gfptr uniform_ptr(const float* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  return (gfptr)(((uint64_t)hi << 32) | lo);
 }
 
 template <int TAPS, int NT, bool VEC>
@@ -57,6 +61,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int H = a.H, W = a.W;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -88,9 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // Source windows as SGPR values. readfirstlane makes them opaque SSA scalars: otherwise LLVM
   // folds select(load kernarg A, load kernarg B) into a per-lane load(select(&A, &B)), i.e. a
   // dependent VMEM access (and a vmcnt(0) drain) in front of every chunk's staging loads.
-  const float* const sp0 = uniform_ptr(a.src[0].p + a.src[0].c0);
-  const float* const sp1 = uniform_ptr((a.nsrc > 1) ? a.src[1].p + a.src[1].c0 : a.src[0].p);
-  const float* const sp2 = uniform_ptr((a.nsrc > 2) ? a.src[2].p + a.src[2].c0 : a.src[0].p);
+  const gfptr sp0 = uniform_ptr(a.src[0].p + a.src[0].c0);
+  const gfptr sp1 = uniform_ptr((a.nsrc > 1) ? a.src[1].p + a.src[1].c0 : a.src[0].p);
+  const gfptr sp2 = uniform_ptr((a.nsrc > 2) ? a.src[2].p + a.src[2].c0 : a.src[0].p);
   const int cs0 = __builtin_amdgcn_readfirstlane(a.src[0].cs), cs1 = __builtin_amdgcn_readfirstlane(a.src[1].cs),
             cs2 = __builtin_amdgcn_readfirstlane(a.src[2].cs);
   const int up0 = __builtin_amdgcn_readfirstlane(a.src[0].up), up1 = __builtin_amdgcn_readfirstlane(a.src[1].up),
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int u = (CHUNK) * 4 + uq;                                                               \
     const bool in0 = u < u0, in1 = u < u1, uok = u < u2;                                          \
     const int ul = in0 ? u : in1 ? (u - u0) : (u - u1);                                           \
-    const float* sp = in0 ? sp0 : in1 ? sp1 : sp2;                                                \
+    gfptr sp = in0 ? sp0 : in1 ? sp1 : sp2;                                                       \
     const int css = in0 ? cs0 : in1 ? cs1 : uok ? cs2 : cs0;                                      \
     const int ups = in0 ? up0 : in1 ? up1 : uok ? up2 : up0;                                      \
     const int nn = in0 ? n0 : in1 ? n1 : n2;                                                      \
@@ -113,10 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int Hs = H >> ups, Ws = W >> ups;                                                       \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       const int y = (pos[s] >> 16) >> ups, x = (pos[s] & 0xffff) >> ups;                          \
-      const float* p = sp + ((size_t)((size_t)b * Hs + y) * Ws + x) * css;                        \
+      gfptr p = sp + ((size_t)((size_t)b * Hs + y) * Ws + x) * css;                               \
       f32x4 v;                                                                                    \
       if (VEC) {                                                                                  \
-        v = *reinterpret_cast<const f32x4*>(p);                                                   \
+        v = *(gf4ptr)(p);                                                                         \
       } else { /* windows that are not 16-byte aligned */                                         \
         v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];                                           \
       }                                                                                           \
@@ -187,6 +193,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
     if (more) HCF_STAGE_WRITE((c + 1) & 1);
     __syncthreads();
+  }
+
+  if (a.dbg && (blockIdx.x & 1023) == 512 && tid == 0) {   // a few mid-grid blocks: shader clock vs 100 MHz reference
+    atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
+    atomicAdd(a.dbg + 1, __builtin_amdgcn_s_memrealtime() - dbg_r0);
   }
 
   // ---- epilogue --------------------------------------------------------------------------------

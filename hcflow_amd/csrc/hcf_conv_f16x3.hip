@@ -1,5 +1,5 @@
 // fp32-equivalent 3x3 convolution on the f16 matrix cores: every fp32 product a*b is formed as
-//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,   x_hi = f16(x), x_lo = f16((x - x_hi) * 2^11) / 2^11
+//   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi,   x_hi = f16(x), x_lo = f16(x - x_hi)
 // (Ootomo-Yokota error-corrected splitting) with fp32 accumulation inside v_mfma_f32_32x32x16_f16.
 // The dropped a_lo*b_lo term and the rounding of the lo parts are ~2^-22 relative, i.e. fp32 class:
 // on the full-depth SR x4 / x8 / rescaling nets the end-to-end deviation from an fp64 evaluation is
@@ -15,9 +15,13 @@
 //   * LDS record per halo pixel: [16 hi halves | 16 lo halves | 16 B pad] = 80 B. The 80-byte pixel
 //     stride makes the ds_read_b128 fragment reads (lane = pixel, 8 halves each) bank-conflict free.
 //   * One LDS stage = one MFMA K (16 channels); 2 stages x 27.2 KB -> up to 3 blocks per CU.
-//   * Weights are pre-split on the host into three f16 streams per (chunk, tap): hi*2^11, lo*2^11 and hi.
-//     Scaling b_hi instead of keeping a second "correction" accumulator keeps ONE fp32 accumulator
-//     per tile: acc = 2^11 * (a_hi b_hi + a_hi b_lo + a_lo b_hi), un-scaled in the epilogue.
+//   * Weights are pre-split on the host into TWO f16 planes per (chunk, tap): P1 = b_hi*2^11 and
+//     P2 = b_lo*2^11 (the 2^11 keeps b_lo's mantissa out of the f16 subnormal range). The activation
+//     lo part is left unscaled (a_lo = f16(a - a_hi), f16 subnormals are kept by the matrix core: its
+//     absolute error is <= 2^-25, i.e. fp32-class for |a| >~ 0.25 and a 3e-8 absolute floor below), so
+//     the third term a_lo*P1 re-uses plane 1: acc = 2^11 (a_hi b_hi + a_hi b_lo + a_lo b_hi) in ONE
+//     fp32 accumulator per tile, un-scaled in the epilogue. Two planes instead of three matter: the
+//     kernel is L1/TA-bandwidth bound on these weight-fragment loads (profiles/r01_f16x3_notes.md).
 //   * Waves: NTB = 2 (33..64 out channels): wave = (row half, n tile), 4 row tiles x 1 n tile each,
 //     so a wave re-uses each weight fragment over 4 MFMA rows; NTB = 1: 4 waves x 2 rows.
 //   * |a| >= 65504 cannot be represented by the hi part: such inputs raise a device flag and the engine
@@ -28,8 +32,14 @@ namespace hcf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space: a pointer rebuilt from SGPR halves would otherwise be "generic" and
+// its loads become flat_load, which also tick lgkmcnt and so serialise with every LDS wait
+typedef const float __attribute__((address_space(1)))* gfptr;
+typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+int g_f16x3_ablation = 0;
 
 namespace f16x3 {
 
@@ -45,15 +55,19 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+__device__ __forceinline__ gfptr uniform_ptr(const float* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  return (gfptr)(((uint64_t)hi << 32) | lo);
 }
 
-template <int TAPS, int NTB, bool VEC>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
+// ABL: timing ablations for tools/conv_bench.py (results are WRONG for ABL != 0; never used by the engine)
+//   bit0 no weight loads in the loop, bit1 no staging after chunk 0, bit2 no LDS fragment reads, bit3 no barrier,
+//   bit4 no MFMA
+template <int TAPS, int NTB, bool VEC, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
+  static_assert(TAPS % 3 == 0, "weight prefetch ring is 3 taps deep");
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   constexpr int NLOAD = HP * (KC / 4);
@@ -65,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const int wm = (NTB == 2) ? (wave >> 1) : wave;   // which group of MT tile rows
   const int wn = (NTB == 2) ? (wave & 1) : 0;       // which 32-channel n tile
   const int H = a.H, W = a.W;
@@ -75,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   const int b = bid / (tiles_x * tiles_y);
   const int x0 = txb * TW, y0 = tyb * TH;
 
-  int pos[NSLOT];
+  int pos[NSLOT], pix0[NSLOT];
   unsigned okmask = 0;
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
@@ -85,15 +101,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const int y = y0 + hy - PAD, x = x0 + hx - PAD;
     const bool ok = y >= 0 && y < H && x >= 0 && x < W;
     okmask |= ok ? (1u << s) : 0u;
-    pos[s] = (min(max(y, 0), H - 1) << 16) | min(max(x, 0), W - 1);
+    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+    pos[s] = (yc << 16) | xc;
+    pix0[s] = (b * H + yc) * W + xc;               // pixel index for sources read at full resolution
   }
   const int uq = tid & 3;
   const int u0 = (a.src[0].n + 3) >> 2;
   const int u1 = u0 + ((a.nsrc > 1) ? ((a.src[1].n + 3) >> 2) : 0);
   const int u2 = u1 + ((a.nsrc > 2) ? ((a.src[2].n + 3) >> 2) : 0);
-  const float* const sp0 = uniform_ptr(a.src[0].p + a.src[0].c0);
-  const float* const sp1 = uniform_ptr((a.nsrc > 1) ? a.src[1].p + a.src[1].c0 : a.src[0].p);
-  const float* const sp2 = uniform_ptr((a.nsrc > 2) ? a.src[2].p + a.src[2].c0 : a.src[0].p);
+  const gfptr sp0 = uniform_ptr(a.src[0].p + a.src[0].c0);
+  const gfptr sp1 = uniform_ptr((a.nsrc > 1) ? a.src[1].p + a.src[1].c0 : a.src[0].p);
+  const gfptr sp2 = uniform_ptr((a.nsrc > 2) ? a.src[2].p + a.src[2].c0 : a.src[0].p);
   const int cs0 = __builtin_amdgcn_readfirstlane(a.src[0].cs), cs1 = __builtin_amdgcn_readfirstlane(a.src[1].cs),
             cs2 = __builtin_amdgcn_readfirstlane(a.src[2].cs);
   const int up0 = __builtin_amdgcn_readfirstlane(a.src[0].up), up1 = __builtin_amdgcn_readfirstlane(a.src[1].up),
@@ -102,13 +120,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
 
   f32x4 stg[NSLOT];
-  bool ovf = false;
 #define HCF_STAGE_LOAD(CHUNK)                                                                     \
   {                                                                                               \
     const int u = (CHUNK) * 4 + uq;                                                               \
     const bool in0 = u < u0, in1 = u < u1, uok = u < u2;                                          \
     const int ul = in0 ? u : in1 ? (u - u0) : (u - u1);                                           \
-    const float* sp = in0 ? sp0 : in1 ? sp1 : sp2;                                                \
+    gfptr sp = in0 ? sp0 : in1 ? sp1 : sp2;                                                       \
     const int css = in0 ? cs0 : in1 ? cs1 : uok ? cs2 : cs0;                                      \
     const int ups = in0 ? up0 : in1 ? up1 : uok ? up2 : up0;                                      \
     const int nn = in0 ? n0 : in1 ? n1 : n2;                                                      \
@@ -116,11 +133,15 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     sp = uok ? sp + 4 * ul : sp0;                                                                 \
     const int Hs = H >> ups, Ws = W >> ups;                                                       \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
-      const int y = (pos[s] >> 16) >> ups, x = (pos[s] & 0xffff) >> ups;                          \
-      const float* p = sp + ((size_t)((size_t)b * Hs + y) * Ws + x) * css;                        \
+      int pidx = pix0[s];                                                                         \
+      if (a.any_up) { /* kernel-uniform: only conv_first reads upsampled windows */               \
+        const int y = (pos[s] >> 16) >> ups, x = (pos[s] & 0xffff) >> ups;                        \
+        pidx = (b * Hs + y) * Ws + x;                                                             \
+      }                                                                                           \
+      gfptr p = sp + (unsigned)(pidx * css); /* launcher guarantees < 2^31 elements per tensor */ \
       f32x4 v;                                                                                    \
       if (VEC) {                                                                                  \
-        v = *reinterpret_cast<const f32x4*>(p);                                                   \
+        v = *(gf4ptr)(p);                                                                         \
       } else {                                                                                    \
         v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];                                           \
       }                                                                                           \
@@ -142,8 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
         const _Float16 h = (_Float16)v[e];                                                        \
         hi[e] = h;                                                                                \
-        lo[e] = (_Float16)((v[e] - (float)h) * SPLIT);                                            \
-        ovf = ovf || !(fabsf(v[e]) < 65504.f);                                                    \
+        lo[e] = (_Float16)(v[e] - (float)h);                                                      \
       }                                                                                           \
       if (q < NLOAD) {                                                                            \
         char* rec = lds + (BUF) * STAGE + (q >> 2) * REC + (q & 3) * 8;                           \
@@ -161,11 +181,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
 
   // B streams: per (chunk, tap) three planes [which][npad][16 halves]; this lane's 8 halves
   const _Float16* wp = reinterpret_cast<const _Float16*>(a.wpack) + (size_t)(wn * 32 + li) * 16 + half * 8;
-  constexpr int WSTEP = 3 * NPAD * 16;              // halves per (chunk, tap)
-  f16x8 bcur[3], bnxt[3];
+  constexpr int WSTEP = 2 * NPAD * 16;              // halves per (chunk, tap): planes P1, P2
+  // 3-tap register ring: the fragment for tap t+2 is requested while tap t computes, and BEFORE the
+  // chunk's staging loads, so the in-order vmcnt never makes a weight wait sit behind HBM latency
+  f16x8 bring[3][2];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bcur[j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
-  wp += WSTEP;
+  for (int d = 0; d < 2; ++d) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bring[d][j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
+    wp += WSTEP;
+  }
 
   // A fragment base (bytes) inside a stage for tile row MT*wm + m
   const int abase = ((MT * wm) * HW + li) * REC + half * 16;
@@ -180,31 +205,53 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
     const bool more = (c + 1 < nchunk);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
+      if (!(ABL & 1)) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) bnxt[j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
+        for (int j = 0; j < 2; ++j) bring[(t + 2) % 3][j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
+      }
       wp += WSTEP;
-      if (t == 0 && more) HCF_STAGE_LOAD(c + 1);
+      if (t == 0 && more && !(ABL & 2)) HCF_STAGE_LOAD(c + 1);
+      // pin the issue point: left alone, the scheduler sinks these loads next to their first use
+      // (two taps later) to save registers, which exposes the full L2/HBM latency on every tap
+      __builtin_amdgcn_sched_barrier(0);
       const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
+      f16x8 ahi[MT], alo[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const char* rec = A + abase + ((m + dy) * HW + dx) * REC;
-        const f16x8 ahi = *reinterpret_cast<const f16x8*>(rec);
-        const f16x8 alo = *reinterpret_cast<const f16x8*>(rec + 32);
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bcur[0], acc[m], 0, 0, 0);   // a_hi * (b_hi 2^11)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bcur[1], acc[m], 0, 0, 0);   // a_hi * (b_lo 2^11)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bcur[2], acc[m], 0, 0, 0);   // (a_lo 2^11) * b_hi
+        if (!(ABL & 4)) {
+          ahi[m] = *reinterpret_cast<const f16x8*>(rec);
+          alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
+        } else {
+          ahi[m] = bring[0][0]; alo[m] = bring[1][1];
+          asm volatile("" : "+v"(ahi[m]), "+v"(alo[m]));
+        }
       }
+      if (ABL & 16) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) bcur[j] = bnxt[j];
+        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ahi[m]), "v"(alo[m]), "v"(bring[t % 3][0]), "v"(bring[t % 3][1]));
+        continue;
+      }
+      // term-major order: consecutive MFMAs hit different accumulators (MT independent chains)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)   // a_hi * (b_hi 2^11)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bring[t % 3][0], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)   // a_hi * (b_lo 2^11)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bring[t % 3][1], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], bring[t % 3][0], acc[m], 0, 0, 0);
     }
-    if (more) HCF_STAGE_WRITE((c + 1) & 1);
-    __syncthreads();
+    if (more && !(ABL & 2)) HCF_STAGE_WRITE((c + 1) & 1);
+    if (!(ABL & 8)) __syncthreads();
   }
 #undef HCF_STAGE_LOAD
 #undef HCF_STAGE_WRITE
 
-  if (__any(ovf)) {
-    if (lane == 0) atomicOr(a.ovf, 1);
+  if (a.dbg && (blockIdx.x & 1023) == 512 && tid == 0) {   // a few mid-grid blocks: shader clock vs 100 MHz reference
+    atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
+    atomicAdd(a.dbg + 1, __builtin_amdgcn_s_memrealtime() - dbg_r0);
   }
 
   // ---- epilogue (same algebra as the fp32 kernel) ---------------------------------------------
@@ -213,6 +260,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a) {
   const bool ocok = oc < cout;
   const float bias = a.bias[oc], scale = a.scale[oc];
   constexpr float UNSPLIT = 1.0f / SPLIT;
+  // Range check: an input with |a| >= 65504 becomes inf in the hi plane and turns every accumulator it
+  // touches into inf / NaN (inf * 0 = NaN), so testing the RAW accumulators is sufficient, and 12x
+  // cheaper than testing every staged element of every chunk.
+  float chk = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);   // stays 0 unless some acc is inf / NaN
+  if (__any(chk != chk)) {
+    if (lane == 0) atomicOr(a.ovf, 1);
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int y = y0 + MT * wm + m;
@@ -238,12 +296,25 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   const long long nblk = (long long)a.B * tiles_x * tiles_y;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;
   bool vec = true;
-  for (int i = 0; i < a.nsrc; ++i)
+  ConvArgs b = a;
+  b.any_up = 0;
+  for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
-  if (vec)
-    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, true>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    if (a.src[i].up) b.any_up = 1;
+    // 32-bit element offsets inside the kernel
+    if ((long long)a.B * (a.H >> a.src[i].up) * (a.W >> a.src[i].up) * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
+  }
+  if (vec && g_f16x3_ablation && TAPS == 9 && NTB == 2) {
+    switch (g_f16x3_ablation) {
+#define HCF_ABL(N) case N: hipLaunchKernelGGL((conv_f16x3_kernel<9, 2, true, N>), dim3((unsigned)nblk), dim3(256), 0, st, b); break;
+      HCF_ABL(1) HCF_ABL(2) HCF_ABL(4) HCF_ABL(8) HCF_ABL(16) HCF_ABL(15) HCF_ABL(3) HCF_ABL(7)
+#undef HCF_ABL
+      default: return HCF_ERR_ARG;
+    }
+  } else if (vec)
+    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else
-    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
@@ -257,8 +328,7 @@ int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st) {
   const int nt = (a.out.n + 31) / 32;
   if (taps == 9 && nt == 1) return f16x3::launch_t<9, 1>(a, st);
   if (taps == 9 && nt == 2) return f16x3::launch_t<9, 2>(a, st);
-  if (taps == 1 && nt == 1) return f16x3::launch_t<1, 1>(a, st);
-  if (taps == 1 && nt == 2) return f16x3::launch_t<1, 2>(a, st);
+  // 1x1 convs (FCN conv2, 2 % of the time) stay on the exact kernel: the 3-tap weight ring needs TAPS % 3 == 0
   return HCF_ERR_UNSUPPORTED;
 }
 

@@ -110,9 +110,9 @@ void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* s
           }
 }
 
-// f16x3 pack for hcf_conv_f16x3.hip: halves [chunk][tap][which(3)][npad][16] with
-// which = { f16(w) * 2^11, f16((w - f16(w)) * 2^11), f16(w) }, plus one zero (chunk,tap) step for the
-// prefetch. Returns false when a weight is too large for the scaled hi plane (|w| * 2^11 >= 65504).
+// f16x3 pack for hcf_conv_f16x3.hip: halves [chunk][tap][plane(2)][npad][16] with
+// planes = { f16(w) * 2^11, f16((w - f16(w)) * 2^11) }, plus two zero (chunk,tap) steps for the
+// prefetch ring. Returns false when a weight is too large for the scaled hi plane (|w| * 2^11 >= 65504).
 bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc,
                              std::vector<float>& pk_as_float, int& nchunk, int& npad) {
   int kv = 0;
@@ -126,8 +126,8 @@ bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const 
     v += ru4(srcs[i]);
     real += srcs[i];
   }
-  const size_t plane = (size_t)npad * 16, step = 3 * plane;
-  std::vector<_Float16> pk(((size_t)nchunk * taps + 1) * step, (_Float16)0.f);
+  const size_t plane = (size_t)npad * 16, step = 2 * plane;
+  std::vector<_Float16> pk(((size_t)nchunk * taps + 2) * step, (_Float16)0.f);   // +2 zero steps: prefetch ring
   for (int ch = 0; ch < nchunk; ++ch)
     for (int t = 0; t < taps; ++t)
       for (int n = 0; n < cout; ++n)
@@ -141,7 +141,6 @@ bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const 
           const size_t o = ((size_t)ch * taps + t) * step + (size_t)n * 16 + e;
           pk[o] = (_Float16)((float)hi * 2048.f);
           pk[o + plane] = lo;
-          pk[o + 2 * plane] = hi;
         }
   pk_as_float.assign((pk.size() + 1) / 2, 0.f);
   memcpy(pk_as_float.data(), pk.data(), pk.size() * sizeof(_Float16));
@@ -263,7 +262,7 @@ struct hcf_engine {
     cv.bias = upload(b);
     cv.scale = upload(s);
     cv.wpack16 = nullptr;
-    if (cv.npad <= 64) {
+    if (cv.npad <= 64 && cv.taps == 9) {
       std::vector<float> pk16;
       int nc = 0, np = 0;
       if (pack_conv_weights_f16x3(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk16, nc, np)) cv.wpack16 = upload(pk16);
@@ -541,7 +540,7 @@ struct hcf_engine {
       hipEventRecord(prof_events[prof_used].e0, st);
     }
     int r;
-    if (use_f16 && cv.wpack16) {
+    if (use_f16 && cv.wpack16 && cv.taps == 9) {
       a.wpack = cv.wpack16;
       a.ovf = ovf_flag;
       r = launch_conv_f16x3(a, cv.taps, st);

@@ -15,6 +15,8 @@ void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* s
 bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc,
                              std::vector<float>& pk_as_float, int& nchunk, int& npad);
 static int g_op_precision = PREC_EXACT;
+static double g_last_clock_mhz = 0;
+extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip
 
 static inline int ru4(int c) { return (c + 3) & ~3; }
 
@@ -42,7 +44,7 @@ static int pack_and_launch(Tmp& t, ConvArgs& a, const float* w, int cin, int cou
                            hipStream_t st, int iters = 1) {
   std::vector<float> pk;
   int nchunk = 0, npad = 0;
-  const bool f16 = (g_op_precision == PREC_F16X3) && cout <= 64;
+  const bool f16 = (g_op_precision == PREC_F16X3) && cout <= 64 && k == 3;
   if (f16) {
     if (!pack_conv_weights_f16x3(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad)) return HCF_ERR_UNSUPPORTED;
     a.ovf = (int*)t.dev(1);
@@ -159,6 +161,11 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
   }
   return rc;
 }
+
+// shader clock (MHz) observed inside the last hcf_bench_conv kernels (s_memtime / s_memrealtime)
+double hcf_debug_last_clock_mhz(void) { return g_last_clock_mhz; }
+// timing ablations of the f16x3 kernel (tools/conv_bench.py --ablate); 0 = off
+int hcf_debug_set_ablation(int32_t bits) { hcf::g_f16x3_ablation = bits; return HCF_OK; }
 
 int hcf_op_set_precision(int32_t mode) {
   if (mode != PREC_EXACT && mode != PREC_F16X3) return HCF_ERR_ARG;
@@ -371,7 +378,10 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
+  a.dbg = (unsigned long long*)t.dev(4);
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 16, st);
   int rc = pack_and_launch(t, a, w.data(), cin, cout, k, srcs, n_src, st);     // pack + warm-up
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 16, st);
   const bool f16 = a.ovf != nullptr;
   hipEventRecord(e0, st);
   for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
@@ -381,6 +391,11 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEventElapsedTime(&ms, e0, e1);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  if (a.dbg) {
+    unsigned long long hd[2] = {0, 0};
+    hipMemcpy(hd, a.dbg, 16, hipMemcpyDeviceToHost);
+    if (hd[1]) g_last_clock_mhz = 100.0 * (double)hd[0] / (double)hd[1];
+  }
   if (ms_per_launch) *ms_per_launch = ms / iters;
   if (flops_per_launch) *flops_per_launch = 2.0 * k * k * cin * (double)cout * B * H * W;
   return rc;

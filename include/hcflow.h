@@ -173,6 +173,9 @@ int hcf_op_gauss_logp(const float* h, const float* x, float* out_logp, int32_t B
 int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t seed, float* out, int32_t B, int32_t C,
                         int32_t H, int32_t W, int32_t rescale, hcf_stream_t stream);
 
+double hcf_debug_last_clock_mhz(void);
+/* tools/conv_bench.py --ablate: timing-only ablations of the f16x3 kernel (results invalid); 0 = off */
+int hcf_debug_set_ablation(int32_t bits);
 /* precision used by the per-op entry points hcf_op_conv2d / hcf_bench_conv (process-wide test knob) */
 int hcf_op_set_precision(int32_t mode);
 /* tools/conv_bench.py: times `iters` back-to-back launches of the conv kernel on random NHWC slabs */

@@ -28,11 +28,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--precision", default="exact", choices=["exact", "f16x3"])
+    ap.add_argument("--ablate", type=int, default=0)
     args = ap.parse_args()
     lib = _lib.load()
-    lib.hcf_bench_conv.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
-    lib.hcf_bench_conv.restype = C.c_int
+    assert lib.hcf_op_set_precision(_lib.Engine.PRECISIONS[args.precision]) == 0
+    peak = 157.3 if args.precision == "exact" else 2500.0 / 3
+    assert lib.hcf_debug_set_ablation(args.ablate) == 0
     torch.cuda.init()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for i, (name, B, H, W, srcs, cout, k) in enumerate(SHAPES):
@@ -42,8 +44,10 @@ def main():
         ms, fl = C.c_double(), C.c_double()
         rc = lib.hcf_bench_conv(B, H, W, arr, len(srcs), cout, k, args.iters, C.byref(ms), C.byref(fl), st)
         assert rc == 0, rc
-        print("%-34s %9.1f us  %7.2f TFLOP/s  (%5.1f %% of 157.3)" % (name, ms.value * 1e3, fl.value / ms.value / 1e9,
-                                                                 100 * fl.value / ms.value / 1e9 / 157.3), flush=True)
+        tf = fl.value / ms.value / 1e9
+        print("%-34s %9.1f us  %7.2f TFLOP/s-equiv  (%5.1f %% of %.1f %s)" % (
+            name, ms.value * 1e3, tf, 100 * tf / peak, peak, args.precision),
+            " clk %.0f MHz" % lib.hcf_debug_last_clock_mhz(), flush=True)
 
 
 if __name__ == "__main__":
