@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec
 GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
 IDEAL_GB_PER_IMAGE = 23.02            # layer-wise-ideal fp32 HBM traffic per image
@@ -43,6 +44,9 @@ def main():
     ap.add_argument("--lr-size", type=int, default=160)
     ap.add_argument("--tau", type=float, default=0.8)
     ap.add_argument("--preset", default="SR_DF2K_4X")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "exact"],
+                    help="conv numerics: f16x3 = fp32-equivalent split products on f16 MFMA (default); exact = fp32 MFMA")
+    ap.add_argument("--no-exact-check", action="store_true", help="skip the exact-fp32 comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=1)
     args = ap.parse_args()
@@ -72,6 +76,7 @@ def main():
         if "ActNorm" in type(m).__name__:
             m.inited = True                      # what HCFlow_SR_model.load() does (:448)
     net = net.to(dev).eval()
+    net.set_precision(args.precision)
 
     B, h = args.batch, args.lr_size
     g = torch.Generator().manual_seed(1000 + rank)
@@ -102,6 +107,26 @@ def main():
         dt = time.perf_counter() - t0
         eng.profile_convs(False)
 
+    # same inputs / same device eps on the exact fp32-MFMA kernels: deviation + exact-mode throughput
+    exact = None
+    if args.precision != "exact" and not args.no_exact_check:
+        with torch.no_grad():
+            torch.manual_seed(1234)
+            y_fast = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+            net.set_precision("exact")
+            torch.manual_seed(1234)
+            y_exact = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)     # also warms the exact path
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+            torch.cuda.synchronize()
+            dte = time.perf_counter() - t1
+            net.set_precision(args.precision)
+        exact = {"max_abs_diff_vs_exact_f32": float((y_fast - y_exact).abs().max()),
+                 "exact_f32_images_per_s_per_gpu": round(B / dte, 3), "tolerance": 1e-4,
+                 "range_fallbacks": net.engine().fallback_count()}
+        del y_fast, y_exact
+
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -114,10 +139,17 @@ def main():
         ms, n, fl = eng.conv_time(9, 2, reset=False)
         ms_all, n_all, fl_all = eng.conv_time(0, 0, reset=True)
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
+        if args.precision == "exact":
+            kname, peak = "conv_mfma_kernel<9,2> (3x3, 64 out-ch, fp32 MFMA 32x32x2)", PEAK_F32_MFMA_TFLOPS
+            pnote = "fp32 matrix peak (MI355X_MICROARCH.md)"
+        else:
+            kname, peak = "conv_f16x3_kernel<9,2> (3x3, 64 out-ch, 3x f16 MFMA 32x32x16 per fp32 product block)", PEAK_F16_MFMA_TFLOPS / 3
+            pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts "
+                     "ALGORITHMIC flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that")
         roofline = {
-            "bound": "mfma", "kernel": "conv_mfma_kernel<9,2> (3x3, 64 out-ch, fp32 MFMA 32x32x2)",
-            "achieved": round(achieved, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "kernel": kname,
+            "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "peak_note": pnote,
+            "frac": round(achieved / peak, 4), "traffic": None,
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / args.steps, 3),
@@ -127,7 +159,8 @@ def main():
         if args.preset == "SR_DF2K_4X" and h == 160:
             per_gpu = img_s / world
             roofline["whole_pass"] = {
-                "mfma_frac": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                "mfma_frac": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / peak, 4),
+                "vs_fp32_mfma_ceiling": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                 "hbm_frac_layerwise_ideal": round(per_gpu * IDEAL_GB_PER_IMAGE / PEAK_HBM_GBS, 4)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -136,13 +169,16 @@ def main():
             "metric": "HR images/sec (inverse sample) DIV2K x4 160px LR", "value": round(img_s, 4),
             "unit": "HR images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "exact" else "f32 via f16x3 split (hi/lo f16 products, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "%s inverse sampling (netG reverse=True), batch %d/GPU, LR %dx%d -> HR %dx%d, "
                                    "tau=%.1f, eps on device, output all-gather over RCCL for N>1"
                                    % (args.preset, B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
                        "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
+            "precision": {"mode": args.precision, "check": exact},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

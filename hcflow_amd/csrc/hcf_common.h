@@ -52,6 +52,7 @@ struct ConvArgs {
   View res2; float rs2;
   int* ovf;                // f16x3 kernel only: device flag raised when an input exceeds the f16 range
   int any_up;              // set by the launcher: some source window is read through an upsample
+  int stagger;             // f16x3 kernel: start-time stagger between co-resident blocks (units of 2048 clocks)
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };
 

@@ -3,28 +3,36 @@
 // (Ootomo-Yokota error-corrected splitting) with fp32 accumulation inside v_mfma_f32_32x32x16_f16.
 // The dropped a_lo*b_lo term and the rounding of the lo parts are ~2^-22 relative, i.e. fp32 class:
 // on the full-depth SR x4 / x8 / rescaling nets the end-to-end deviation from an fp64 evaluation is
-// 4.4e-6 .. 5.6e-6 versus 3.1e-6 .. 4.4e-6 for plain fp32 (tools/split_precision_check.py), far inside
+// 3.8e-6 .. 5.5e-6 versus 3.1e-6 .. 4.4e-6 for plain fp32 (tools/split_precision_check.py), far inside
 // the 1e-4 parity gate of BASELINE.json. f16 MFMA runs at 16x the fp32 MFMA rate, so three of them per
-// fp32-equivalent K=16 step lift the compute ceiling 5.3x (157 -> 833 TFLOP/s-equivalent).
+// fp32-equivalent K=16 step lift the compute ceiling 5.3x (157 -> 833 TFLOP/s-equivalent at 2.4 GHz;
+// the chip sustains ~1.45-1.6 GHz under this load, see profiles/).
 //
-// Layout choices
-//   * HBM tensors stay plain fp32 NHWC (same Views, same epilogue as hcf_conv.hip). The split happens
-//     once per staged element, in registers, between the global load and the LDS write (~3 VALU per
-//     element, hidden under the other waves' MFMAs); every staged element is then reused by 9 taps x
-//     32..64 output channels.
-//   * LDS record per halo pixel: [16 hi halves | 16 lo halves | 16 B pad] = 80 B. The 80-byte pixel
-//     stride makes the ds_read_b128 fragment reads (lane = pixel, 8 halves each) bank-conflict free.
-//   * One LDS stage = one MFMA K (16 channels); 2 stages x 27.2 KB -> up to 3 blocks per CU.
-//   * Weights are pre-split on the host into TWO f16 planes per (chunk, tap): P1 = b_hi*2^11 and
-//     P2 = b_lo*2^11 (the 2^11 keeps b_lo's mantissa out of the f16 subnormal range). The activation
-//     lo part is left unscaled (a_lo = f16(a - a_hi), f16 subnormals are kept by the matrix core: its
-//     absolute error is <= 2^-25, i.e. fp32-class for |a| >~ 0.25 and a 3e-8 absolute floor below), so
-//     the third term a_lo*P1 re-uses plane 1: acc = 2^11 (a_hi b_hi + a_hi b_lo + a_lo b_hi) in ONE
-//     fp32 accumulator per tile, un-scaled in the epilogue. Two planes instead of three matter: the
-//     kernel is L1/TA-bandwidth bound on these weight-fragment loads (profiles/r01_f16x3_notes.md).
-//   * Waves: NTB = 2 (33..64 out channels): wave = (row half, n tile), 4 row tiles x 1 n tile each,
-//     so a wave re-uses each weight fragment over 4 MFMA rows; NTB = 1: 4 waves x 2 rows.
-//   * |a| >= 65504 cannot be represented by the hi part: such inputs raise a device flag and the engine
+// Structure (one block = 256 threads = 4 waves, output tile 8 rows x 32 cols x 32*NTB channels)
+//   * HBM tensors stay plain fp32 NHWC (same Views / epilogue as hcf_conv.hip). The activation split
+//     happens once per staged element, in registers, between the global load and the LDS write;
+//     every staged element is then reused by 9 taps x 32..64 output channels.
+//   * K is walked in chunks of 16 channels = one MFMA K. Per chunk LDS holds
+//       A: the 10 x 34 halo tile as 80-byte records [16 hi halves | 16 lo halves | 16 B pad]
+//          (the 80-byte pixel stride makes the ds_read_b128 fragment reads conflict-free), 27.2 KB
+//       B: the chunk's weights for all 9 taps, two f16 planes P1 = b_hi*2^11, P2 = b_lo*2^11 laid out
+//          [tap][plane][k-half][n][8 halves] (conflict-free fragment reads), 18.4 KB * NTB.
+//     v1 of this kernel fetched B fragments per wave straight from global memory: with 4 waves
+//     fetching identical (NTB=1) or pairwise identical (NTB=2) fragments it was L1/TA-bandwidth
+//     bound (~130 KB through a 64 B/clk L1 per chunk). Staging B once per block through LDS cuts L1
+//     traffic 2.4x / 1.6x; LDS read bandwidth (256 B/clk) has the headroom.
+//   * LDS is single-buffered (45.6 / 64 KB -> 3 / 2 blocks per CU); the NEXT chunk travels in
+//     registers: its global loads are issued before the chunk's 27*MT MFMAs, converted after them,
+//     and written between two barriers (only ds_writes sit between the barriers; the other resident
+//     blocks keep the matrix cores busy meanwhile).
+//   * The activation lo part is left unscaled (f16 subnormals are kept by the matrix core: absolute
+//     error <= 2^-25, fp32-class for |a| >~ 0.25 and a 3e-8 absolute floor below), so the third term
+//     a_lo*P1 re-uses plane 1 and ONE fp32 accumulator per tile holds 2^11 (a_hi b_hi + a_hi b_lo +
+//     a_lo b_hi); the 2^-11 is applied in the epilogue.
+//   * Waves: NTB = 2 (33..64 out channels): wave = (row half, n tile), 4 row tiles each;
+//     NTB = 1: 4 waves x 2 row tiles.
+//   * |a| >= 65504 cannot be represented by the hi part and turns the accumulators it touches into
+//     inf / NaN; the epilogue tests the raw accumulators and raises a device flag, upon which the engine
 //     re-runs the pass on the exact fp32 kernel (hcf_conv.hip).
 #include "hcf_common.h"
 
@@ -32,14 +40,14 @@ namespace hcf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // explicit global address space: a pointer rebuilt from SGPR halves would otherwise be "generic" and
 // its loads become flat_load, which also tick lgkmcnt and so serialise with every LDS wait
 typedef const float __attribute__((address_space(1)))* gfptr;
 typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-int g_f16x3_ablation = 0;
+int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N: start stagger (x 2048 clocks) between co-resident blocks
 
 namespace f16x3 {
 
@@ -62,20 +70,23 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
   return (gfptr)(((uint64_t)hi << 32) | lo);
 }
 
-// ABL: timing ablations for tools/conv_bench.py (results are WRONG for ABL != 0; never used by the engine)
-//   bit0 no weight loads in the loop, bit1 no staging after chunk 0, bit2 no LDS fragment reads, bit3 no barrier,
-//   bit4 no MFMA
-template <int TAPS, int NTB, bool VEC, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
-  static_assert(TAPS % 3 == 0, "weight prefetch ring is 3 taps deep");
-  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+// UP: some source window is read through a nearest upsample (conv_first only); compile-time so that the
+// staging macro is straight-line code (control flow inside it makes the waitcnt insertion serialise the loads)
+template <int NTB, bool VEC, bool UP>
+__global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(const ConvArgs a) {
+  constexpr int TAPS = 9, PAD = 1;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   constexpr int NLOAD = HP * (KC / 4);
-  constexpr int NSLOT = (NLOAD + 255) / 256;
+  constexpr int NSLOT = (NLOAD + 255) / 256;        // float4 staging slots per thread (A)
   constexpr int NPAD = NTB * 32;
   constexpr int MT = 2 * NTB;                       // 32-pixel row tiles per wave
-  constexpr int STAGE = HP * REC;                   // bytes
-  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+  constexpr int A_BYTES = HP * REC;
+  constexpr int BHALF = NPAD * 16;                  // bytes of one (tap, plane, k-half): n x 8 halves
+  constexpr int B_BYTES = TAPS * 2 * 2 * BHALF;     // per chunk
+  constexpr int BV = B_BYTES / 16;                  // float4 units
+  constexpr int BSLOT = (BV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
+  char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
@@ -118,8 +129,11 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
             up2 = __builtin_amdgcn_readfirstlane(a.src[2].up);
   const int n0 = __builtin_amdgcn_readfirstlane(a.src[0].n), n1 = __builtin_amdgcn_readfirstlane(a.src[1].n),
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
+  const gf4ptr wq = (gf4ptr)uniform_ptr(a.wpack) + tid;   // this thread's float4 lane of the weight stream
 
-  f32x4 stg[NSLOT];
+  int stg_valid = 0;       // valid channels (0..4+) of this thread's 4-channel unit in the staged chunk
+  f32x4 stg[NSLOT];        // next chunk's activations: fp32 after the load, (hi, lo) f16 pairs after the split
+  f32x4 stb[BSLOT];        // next chunk's weights (already split on the host)
 #define HCF_STAGE_LOAD(CHUNK)                                                                     \
   {                                                                                               \
     const int u = (CHUNK) * 4 + uq;                                                               \
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
     const int Hs = H >> ups, Ws = W >> ups;                                                       \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       int pidx = pix0[s];                                                                         \
-      if (a.any_up) { /* kernel-uniform: only conv_first reads upsampled windows */               \
+      if (UP) {                                                                                    \
         const int y = (pos[s] >> 16) >> ups, x = (pos[s] & 0xffff) >> ups;                        \
         pidx = (b * Hs + y) * Ws + x;                                                             \
       }                                                                                           \
@@ -145,31 +159,49 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
       } else {                                                                                    \
         v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];                                           \
       }                                                                                           \
-      const bool ok = (okmask >> s) & 1u;                                                         \
-      v.x = (ok && valid > 0) ? v.x : 0.f;                                                        \
-      v.y = (ok && valid > 1) ? v.y : 0.f;                                                        \
-      v.z = (ok && valid > 2) ? v.z : 0.f;                                                        \
-      v.w = (ok && valid > 3) ? v.w : 0.f;                                                        \
-      stg[s] = v;                                                                                 \
+      stg[s] = v; /* RAW load result: nothing here may consume it, or the wave waits for HBM now */ \
+    }                                                                                             \
+    stg_valid = valid;                                                                            \
+    _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
+      const int q = tid + 256 * s;                                                                \
+      stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? 256 * s : 0)];                               \
     }                                                                                             \
   }
-  // split in registers, then two 8-byte LDS writes per staged float4 (hi half-plane, lo half-plane)
-#define HCF_STAGE_WRITE(BUF)                                                                      \
+  // split in registers (VALU only): stg[s] <- {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves
+#define HCF_STAGE_SPLIT()                                                                         \
+  {                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
+      f32x4 v = stg[s];                                                                           \
+      const bool ok = (okmask >> s) & 1u; /* zero padding of the conv + channel tail of the window */ \
+      v.x = (ok && stg_valid > 0) ? v.x : 0.f;                                                    \
+      v.y = (ok && stg_valid > 1) ? v.y : 0.f;                                                    \
+      v.z = (ok && stg_valid > 2) ? v.z : 0.f;                                                    \
+      v.w = (ok && stg_valid > 3) ? v.w : 0.f;                                                    \
+      union { f16x4 h[2]; f32x4 f; } u_;                                                          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+        const _Float16 h = (_Float16)v[e];                                                        \
+        u_.h[0][e] = h;                                                                           \
+        u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                 \
+      }                                                                                           \
+      stg[s] = u_.f;                                                                              \
+    }                                                                                             \
+  }
+  // only LDS writes: two 8-byte pieces per activation slot (hi half-plane, lo half-plane), 16 B per weight slot
+#define HCF_STAGE_WRITE()                                                                         \
   {                                                                                               \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       const int q = tid + 256 * s;                                                                \
-      const f32x4 v = stg[s];                                                                     \
-      f16x4 hi, lo;                                                                               \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-        const _Float16 h = (_Float16)v[e];                                                        \
-        hi[e] = h;                                                                                \
-        lo[e] = (_Float16)(v[e] - (float)h);                                                      \
-      }                                                                                           \
       if (q < NLOAD) {                                                                            \
-        char* rec = lds + (BUF) * STAGE + (q >> 2) * REC + (q & 3) * 8;                           \
-        *reinterpret_cast<f16x4*>(rec) = hi;                                                      \
-        *reinterpret_cast<f16x4*>(rec + 32) = lo;                                                 \
+        char* rec = lds + (q >> 2) * REC + (q & 3) * 8;                                           \
+        union { f16x4 h[2]; f32x4 f; } u_;                                                        \
+        u_.f = stg[s];                                                                            \
+        *reinterpret_cast<f16x4*>(rec) = u_.h[0];                                                 \
+        *reinterpret_cast<f16x4*>(rec + 32) = u_.h[1];                                            \
       }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
+      const int q = tid + 256 * s;                                                                \
+      if (q < BV) *reinterpret_cast<f32x4*>(ldsB + q * 16) = stb[s];                              \
     }                                                                                             \
   }
 
@@ -179,74 +211,52 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  // B streams: per (chunk, tap) three planes [which][npad][16 halves]; this lane's 8 halves
-  const _Float16* wp = reinterpret_cast<const _Float16*>(a.wpack) + (size_t)(wn * 32 + li) * 16 + half * 8;
-  constexpr int WSTEP = 2 * NPAD * 16;              // halves per (chunk, tap): planes P1, P2
-  // 3-tap register ring: the fragment for tap t+2 is requested while tap t computes, and BEFORE the
-  // chunk's staging loads, so the in-order vmcnt never makes a weight wait sit behind HBM latency
-  f16x8 bring[3][2];
-#pragma unroll
-  for (int d = 0; d < 2; ++d) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bring[d][j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
-    wp += WSTEP;
-  }
-
-  // A fragment base (bytes) inside a stage for tile row MT*wm + m
+  // fragment bases (bytes): A for tile row MT*wm + m, B for this wave's n tile
   const int abase = ((MT * wm) * HW + li) * REC + half * 16;
+  const int bbase = half * BHALF + (wn * 32 + li) * 16;
 
   HCF_STAGE_LOAD(0);
-  HCF_STAGE_WRITE(0);
+  HCF_STAGE_SPLIT();
+  HCF_STAGE_WRITE();
   __syncthreads();
 
   const int nchunk = a.nchunk;
   for (int c = 0; c < nchunk; ++c) {
-    const char* A = lds + (c & 1) * STAGE;
     const bool more = (c + 1 < nchunk);
+    if (more) HCF_STAGE_LOAD(c + 1);               // global loads fly under this chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      if (!(ABL & 1)) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bring[(t + 2) % 3][j] = *reinterpret_cast<const f16x8*>(wp + j * NPAD * 16);
-      }
-      wp += WSTEP;
-      if (t == 0 && more && !(ABL & 2)) HCF_STAGE_LOAD(c + 1);
-      // pin the issue point: left alone, the scheduler sinks these loads next to their first use
-      // (two taps later) to save registers, which exposes the full L2/HBM latency on every tap
-      __builtin_amdgcn_sched_barrier(0);
-      const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
+      const int dy = t / 3, dx = t % 3;
+      const char* bt = ldsB + bbase + t * (4 * BHALF);
+      const f16x8 b1 = *reinterpret_cast<const f16x8*>(bt);               // P1 = b_hi * 2^11
+      const f16x8 b2 = *reinterpret_cast<const f16x8*>(bt + 2 * BHALF);   // P2 = b_lo * 2^11
       f16x8 ahi[MT], alo[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const char* rec = A + abase + ((m + dy) * HW + dx) * REC;
-        if (!(ABL & 4)) {
-          ahi[m] = *reinterpret_cast<const f16x8*>(rec);
-          alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
-        } else {
-          ahi[m] = bring[0][0]; alo[m] = bring[1][1];
-          asm volatile("" : "+v"(ahi[m]), "+v"(alo[m]));
-        }
-      }
-      if (ABL & 16) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(ahi[m]), "v"(alo[m]), "v"(bring[t % 3][0]), "v"(bring[t % 3][1]));
-        continue;
+        const char* rec = lds + abase + ((m + dy) * HW + dx) * REC;
+        ahi[m] = *reinterpret_cast<const f16x8*>(rec);
+        alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
       }
       // term-major order: consecutive MFMAs hit different accumulators (MT independent chains)
 #pragma unroll
       for (int m = 0; m < MT; ++m)   // a_hi * (b_hi 2^11)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bring[t % 3][0], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], b1, acc[m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)   // a_hi * (b_lo 2^11)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], bring[t % 3][1], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], b2, acc[m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], bring[t % 3][0], acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
     }
-    if (more && !(ABL & 2)) HCF_STAGE_WRITE((c + 1) & 1);
-    if (!(ABL & 8)) __syncthreads();
+    if (!more) break;
+    HCF_STAGE_SPLIT();                             // VALU only, before the barrier
+    __syncthreads();                               // every wave has finished reading this chunk
+    HCF_STAGE_WRITE();
+    __syncthreads();
   }
 #undef HCF_STAGE_LOAD
+#undef HCF_STAGE_SPLIT
 #undef HCF_STAGE_WRITE
 
   if (a.dbg && (blockIdx.x & 1023) == 512 && tid == 0) {   // a few mid-grid blocks: shader clock vs 100 MHz reference
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(const ConvArgs a) {
   }
 }
 
-template <int TAPS, int NTB>
+template <int NTB>
 static int launch_t(const ConvArgs& a, hipStream_t st) {
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const long long nblk = (long long)a.B * tiles_x * tiles_y;
@@ -298,23 +308,19 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
+  b.stagger = g_f16x3_ablation;
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
     if (a.src[i].up) b.any_up = 1;
     // 32-bit element offsets inside the kernel
     if ((long long)a.B * (a.H >> a.src[i].up) * (a.W >> a.src[i].up) * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
   }
-  if (vec && g_f16x3_ablation && TAPS == 9 && NTB == 2) {
-    switch (g_f16x3_ablation) {
-#define HCF_ABL(N) case N: hipLaunchKernelGGL((conv_f16x3_kernel<9, 2, true, N>), dim3((unsigned)nblk), dim3(256), 0, st, b); break;
-      HCF_ABL(1) HCF_ABL(2) HCF_ABL(4) HCF_ABL(8) HCF_ABL(16) HCF_ABL(15) HCF_ABL(3) HCF_ABL(7)
-#undef HCF_ABL
-      default: return HCF_ERR_ARG;
-    }
-  } else if (vec)
-    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  if (vec && !b.any_up)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  else if (vec)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else
-    hipLaunchKernelGGL((conv_f16x3_kernel<TAPS, NTB, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
@@ -326,9 +332,9 @@ int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st) {
   for (int i = 0; i < a.nsrc; ++i)
     if ((a.H >> a.src[i].up) << a.src[i].up != a.H || (a.W >> a.src[i].up) << a.src[i].up != a.W) return HCF_ERR_ARG;
   const int nt = (a.out.n + 31) / 32;
-  if (taps == 9 && nt == 1) return f16x3::launch_t<9, 1>(a, st);
-  if (taps == 9 && nt == 2) return f16x3::launch_t<9, 2>(a, st);
-  // 1x1 convs (FCN conv2, 2 % of the time) stay on the exact kernel: the 3-tap weight ring needs TAPS % 3 == 0
+  if (taps == 9 && nt == 1) return f16x3::launch_t<1>(a, st);
+  if (taps == 9 && nt == 2) return f16x3::launch_t<2>(a, st);
+  // 1x1 convs (FCN conv2) and > 64 output channels stay on the exact kernel
   return HCF_ERR_UNSUPPORTED;
 }
 

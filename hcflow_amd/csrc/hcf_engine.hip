@@ -110,9 +110,9 @@ void pack_conv_weights(const float* w, int cin, int cout, int taps, const int* s
           }
 }
 
-// f16x3 pack for hcf_conv_f16x3.hip: halves [chunk][tap][plane(2)][npad][16] with
-// planes = { f16(w) * 2^11, f16((w - f16(w)) * 2^11) }, plus two zero (chunk,tap) steps for the
-// prefetch ring. Returns false when a weight is too large for the scaled hi plane (|w| * 2^11 >= 65504).
+// f16x3 pack for hcf_conv_f16x3.hip: halves [chunk][tap][plane(2)][k-half(2)][npad][8] with
+// plane 0 = f16(w) * 2^11, plane 1 = f16((w - f16(w)) * 2^11); a chunk is one contiguous block that the
+// kernel copies linearly into LDS. Returns false when a weight is too large for the scaled hi plane.
 bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const int* srcs, int nsrc,
                              std::vector<float>& pk_as_float, int& nchunk, int& npad) {
   int kv = 0;
@@ -126,8 +126,8 @@ bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const 
     v += ru4(srcs[i]);
     real += srcs[i];
   }
-  const size_t plane = (size_t)npad * 16, step = 2 * plane;
-  std::vector<_Float16> pk(((size_t)nchunk * taps + 2) * step, (_Float16)0.f);   // +2 zero steps: prefetch ring
+  const size_t khalf = (size_t)npad * 8, plane = 2 * khalf, tapsz = 2 * plane, chunksz = (size_t)taps * tapsz;
+  std::vector<_Float16> pk(((size_t)nchunk + 1) * chunksz, (_Float16)0.f);   // +1 zero chunk: over-read slack
   for (int ch = 0; ch < nchunk; ++ch)
     for (int t = 0; t < taps; ++t)
       for (int n = 0; n < cout; ++n)
@@ -138,7 +138,7 @@ bool pack_conv_weights_f16x3(const float* w, int cin, int cout, int taps, const 
           if (!(fabsf(x) * 2048.f < 60000.f)) return false;
           const _Float16 hi = (_Float16)x;
           const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
-          const size_t o = ((size_t)ch * taps + t) * step + (size_t)n * 16 + e;
+          const size_t o = (size_t)ch * chunksz + (size_t)t * tapsz + (size_t)(e >> 3) * khalf + (size_t)n * 8 + (e & 7);
           pk[o] = (_Float16)((float)hi * 2048.f);
           pk[o + plane] = lo;
         }
