@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int n0 = __builtin_amdgcn_readfirstlane(a.src[0].n), n1 = __builtin_amdgcn_readfirstlane(a.src[1].n),
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
 
+  int stg_valid = 0;
   f32x4 stg[NSLOT];
 #define HCF_STAGE_LOAD(CHUNK)                                                                     \
   {                                                                                               \
@@ -126,19 +127,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       } else { /* windows that are not 16-byte aligned */                                         \
         v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];                                           \
       }                                                                                           \
-      const bool ok = (okmask >> s) & 1u;                                                         \
-      v.x = (ok && valid > 0) ? v.x : 0.f;                                                        \
-      v.y = (ok && valid > 1) ? v.y : 0.f;                                                        \
-      v.z = (ok && valid > 2) ? v.z : 0.f;                                                        \
-      v.w = (ok && valid > 3) ? v.w : 0.f;                                                        \
-      stg[s] = v;                                                                                 \
+      stg[s] = v; /* RAW load result: consuming it here would make the wave wait for HBM now */   \
     }                                                                                             \
+    stg_valid = valid;                                                                            \
   }
 #define HCF_STAGE_WRITE(BUF)                                                                      \
   {                                                                                               \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       const int q = tid + 256 * s;                                                                \
-      if (q < NLOAD) *reinterpret_cast<f32x4*>(&lds[(BUF)][q * 4]) = stg[s];                      \
+      f32x4 v = stg[s];                                                                           \
+      const bool ok = (okmask >> s) & 1u; /* conv zero padding + channel tail of the window */    \
+      v.x = (ok && stg_valid > 0) ? v.x : 0.f;                                                    \
+      v.y = (ok && stg_valid > 1) ? v.y : 0.f;                                                    \
+      v.z = (ok && stg_valid > 2) ? v.z : 0.f;                                                    \
+      v.w = (ok && stg_valid > 3) ? v.w : 0.f;                                                    \
+      if (q < NLOAD) *reinterpret_cast<f32x4*>(&lds[(BUF)][q * 4]) = v;                           \
     }                                                                                             \
   }
 
@@ -174,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) bnxt[n] = *reinterpret_cast<const f32x4*>(wp + n * 32 * 8);
       wp += NPAD * 8;
-      if (s == 0 && more) HCF_STAGE_LOAD(c + 1);       // global loads fly under this chunk's MFMAs
+      if (s == 0 && more) {
+        HCF_STAGE_LOAD(c + 1);                     // global loads fly under this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);         // ... provided they are ISSUED here and not sunk to the LDS write
+      }
       const int tap = s >> 1, kg = s & 1;
       const int dy = (TAPS == 9) ? tap / 3 : 0, dx = (TAPS == 9) ? tap % 3 : 0;
       f32x4 af[2];
