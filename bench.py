@@ -136,8 +136,17 @@ def main():
     if rank == 0:
         img_s = world * B * args.steps / dt
         # dominant kernel: 3x3 conv with 2 N-tiles (64 output channels): RRDB conv5 / FCN conv1
-        ms, n, fl = eng.conv_time(9, 2, reset=False)
-        ms_all, n_all, fl_all = eng.conv_time(0, 0, reset=True)
+        ms, n, fl, by = eng.conv_time(9, 2, reset=False)
+        ms_all, n_all, fl_all, by_all = eng.conv_time(0, 0, reset=True)
+        traffic, traffic_note = None, None
+        try:    # HBM bytes per launch from a separate rocprofv3 --pmc pass over this same command (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))
+            key = "f16x3<2>" if args.precision != "exact" else "exact<9,2>"
+            if key in tj["kernels"] and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
+                traffic = round(tj["kernels"][key]["hbm_bytes_per_launch"] / 1e9, 4)
+                traffic_note = "GB per launch, " + tj["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         if args.precision == "exact":
             kname, peak = "conv_mfma_kernel<9,2> (3x3, 64 out-ch, fp32 MFMA 32x32x2)", PEAK_F32_MFMA_TFLOPS
@@ -149,7 +158,8 @@ def main():
         roofline = {
             "bound": "mfma", "kernel": kname,
             "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "peak_note": pnote,
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_GB_per_launch": round(by / max(n, 1) / 1e9, 4),
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / args.steps, 3),

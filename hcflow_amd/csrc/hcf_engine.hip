@@ -164,7 +164,7 @@ struct hcf_engine {
   std::string err;
   // conv profiling
   bool prof = false;
-  struct ProfRec { hipEvent_t e0, e1; int taps, nt; double flops; };
+  struct ProfRec { hipEvent_t e0, e1; int taps, nt; double flops, bytes; };
   std::vector<ProfRec> prof_events;
   size_t prof_used = 0;
   // build state
@@ -537,6 +537,11 @@ struct hcf_engine {
       prof_events[prof_used].taps = cv.taps;
       prof_events[prof_used].nt = cv.npad / 32;
       prof_events[prof_used].flops = cv.flops_per_pixel * (double)B_ * H * W;
+      {   // algorithmic HBM bytes: every source window read once, output written once, residuals read once, weights once
+        double px_bytes = 4.0 * cv.cout * (1 + (res1.p ? 1 : 0) + (res2.p ? 1 : 0));
+        for (int i = 0; i < cv.nsrc; ++i) px_bytes += 4.0 * cv.src_n[i] / (double)(1 << (2 * srcs[i].up));
+        prof_events[prof_used].bytes = px_bytes * (double)B_ * H * W + cv.flops_per_pixel * 2.0;   // + weights (4 B each)
+      }
       hipEventRecord(prof_events[prof_used].e0, st);
     }
     int r;
@@ -1046,9 +1051,9 @@ int hcf_profile_convs(hcf_engine* e, int enable) {
 }
 
 int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t reset, double* total_ms, int64_t* launches,
-                     double* flops) {
+                     double* flops, double* bytes) {
   if (!e) return HCF_ERR_ARG;
-  double tot = 0, fl = 0;
+  double tot = 0, fl = 0, by = 0;
   int64_t n = 0;
   for (size_t i = 0; i < e->prof_used; ++i) {
     const auto& r = e->prof_events[i];
@@ -1058,11 +1063,13 @@ int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t reset, dou
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return HCF_ERR_HIP;
     tot += ms;
     fl += r.flops;
+    by += r.bytes;
     n++;
   }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = n;
   if (flops) *flops = fl;
+  if (bytes) *bytes = by;
   if (reset) e->prof_used = 0;
   return HCF_OK;
 }
