@@ -52,7 +52,10 @@ struct ConvArgs {
   View res2; float rs2;
   int* ovf;                // f16x3 kernel only: device flag raised when an input exceeds the f16 range
   int any_up;              // set by the launcher: some source window is read through an upsample
-  int stagger;             // f16x3 kernel: start-time stagger between co-resident blocks (units of 2048 clocks)
+  // f16x3 kernel, optional fused second layer (FCN conv2: 1x1, 64 -> 64): out = act2((W2 * act(layer1) + bias2) * scale2)
+  const float* w2;         // f16x3 pack of the 1x1 weights (taps = 1) or nullptr
+  const float* bias2; const float* scale2; int act2;
+  int stagger;             // unused
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };
 

@@ -72,8 +72,12 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 
 // UP: some source window is read through a nearest upsample (conv_first only); compile-time so that the
 // staging macro is straight-line code (control flow inside it makes the waitcnt insertion serialise the loads)
-template <int NTB, bool VEC, bool UP>
+// FUSE2 (NTB = 2 only): the block also applies the FCN's second layer (Basic.py:443-444), a 1x1 conv 64 -> 64 with
+// ActNorm + ReLU, to its own output tile before storing: relu(AN1(conv3x3)) goes to LDS as split f16, 48 more MFMAs
+// per wave form the 64 x 64 GEMM, and only H2 is written to HBM (the stand-alone 1x1 kernel was HBM-bound).
+template <int NTB, bool VEC, bool UP, bool FUSE2 = false>
 __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(const ConvArgs a) {
+  static_assert(!FUSE2 || NTB == 2, "the fused 1x1 layer needs all 64 channels of the tile in one block");
   constexpr int TAPS = 9, PAD = 1;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   constexpr int NLOAD = HP * (KC / 4);
@@ -85,7 +89,9 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   constexpr int B_BYTES = TAPS * 2 * 2 * BHALF;     // per chunk
   constexpr int BV = B_BYTES / 16;                  // float4 units
   constexpr int BSLOT = (BV + 255) / 256;
-  __shared__ __attribute__((aligned(16))) char lds[A_BYTES + B_BYTES];
+  constexpr int F2_BYTES = FUSE2 ? (TH * TW) * 4 * 64 : 0;      // [256 px][4 k-chunks][16 hi | 16 lo]
+  constexpr int LDS_BYTES = (A_BYTES + B_BYTES > F2_BYTES) ? (A_BYTES + B_BYTES) : F2_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
@@ -268,7 +274,6 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   const int cout = a.out.n;
   const int oc = wn * 32 + li;
   const bool ocok = oc < cout;
-  const float bias = a.bias[oc], scale = a.scale[oc];
   constexpr float UNSPLIT = 1.0f / SPLIT;
   // Range check: an input with |a| >= 65504 becomes inf in the hi plane and turns every accumulator it
   // touches into inf / NaN (inf * 0 = NaN), so testing the RAW accumulators is sufficient, and 12x
@@ -278,9 +283,63 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);   // stays 0 unless some acc is inf / NaN
+
+  if constexpr (FUSE2) {
+    // layer 1 epilogue -> split f16 A operand in LDS: record (px, kc) = [16 hi | 16 lo] halves of channels 16kc..16kc+15
+    {
+      const float bias1 = a.bias[oc], scale1 = a.scale[oc];
+      __syncthreads();                               // every wave is done with the staging buffers
+      const int kc = oc >> 4, kpos = oc & 15;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = (acc[m][r] * UNSPLIT + bias1) * scale1;
+          if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          const _Float16 h = (_Float16)v;
+          char* rec = lds + (px * 4 + kc) * 64 + kpos * 2;
+          *reinterpret_cast<_Float16*>(rec) = h;
+          *reinterpret_cast<_Float16*>(rec + 32) = (_Float16)(v - (float)h);
+        }
+      __syncthreads();
+    }
+    // layer 2: acc = sum over 4 k-chunks; weights [kc][plane][k-half][64 n][8 halves] straight from L1/L2 (8 KB per wave)
+    const _Float16* w2 = reinterpret_cast<const _Float16*>(a.w2) + (size_t)half * (64 * 8) + (size_t)(wn * 32 + li) * 8;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const f16x8 b1 = *reinterpret_cast<const f16x8*>(w2 + (size_t)(kc * 2 + 0) * (2 * 64 * 8));
+      const f16x8 b2 = *reinterpret_cast<const f16x8*>(w2 + (size_t)(kc * 2 + 1) * (2 * 64 * 8));
+      f16x8 ahi[MT], alo[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const char* rec = lds + (((MT * wm + m) * TW + li) * 4 + kc) * 64 + half * 16;
+        ahi[m] = *reinterpret_cast<const f16x8*>(rec);
+        alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], b1, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], b2, acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);
+  }
   if (__any(chk != chk)) {
     if (lane == 0) atomicOr(a.ovf, 1);
   }
+
+  const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
+  const int act = FUSE2 ? a.act2 : a.act;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int y = y0 + MT * wm + m;
@@ -290,8 +349,8 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
       if (ocok && y < H && x < W) {
         const size_t pix = (size_t)((size_t)b * H + y) * W + x;
         float v = (acc[m][r] * UNSPLIT + bias) * scale;
-        if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+        if (act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
         if (a.res1.p) v = v * a.rs1 + a.res1.p[pix * a.res1.cs + a.res1.c0 + oc];
         if (a.res2.p) v = v * a.rs2 + a.res2.p[pix * a.res2.cs + a.res2.c0 + oc];
         a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
@@ -315,7 +374,17 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     // 32-bit element offsets inside the kernel
     if ((long long)a.B * (a.H >> a.src[i].up) * (a.W >> a.src[i].up) * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
   }
-  if (vec && !b.any_up)
+  if (a.w2) {      // fused FCN conv1 + conv2
+    if constexpr (NTB == 2) {
+      if (!vec || a.out.n != 64 || !a.bias2 || !a.scale2 || a.res1.p || a.res2.p) return HCF_ERR_ARG;
+      if (b.any_up)
+        hipLaunchKernelGGL((conv_f16x3_kernel<2, true, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else
+        hipLaunchKernelGGL((conv_f16x3_kernel<2, true, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    } else {
+      return HCF_ERR_ARG;
+    }
+  } else if (vec && !b.any_up)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else if (vec)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);

@@ -262,7 +262,7 @@ struct hcf_engine {
     cv.bias = upload(b);
     cv.scale = upload(s);
     cv.wpack16 = nullptr;
-    if (cv.npad <= 64 && cv.taps == 9) {
+    if (cv.npad <= 64) {      // 1x1 packs are only used fused into a preceding 3x3 (FCN conv1 + conv2)
       std::vector<float> pk16;
       int nc = 0, np = 0;
       if (pack_conv_weights_f16x3(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk16, nc, np)) cv.wpack16 = upload(pk16);
@@ -510,8 +510,14 @@ struct hcf_engine {
 
   int B_ = 0;   // batch of the running pass
 
+  // f16x3 mode can run FCN conv1 (3x3 -> 64) and conv2 (1x1 64 -> 64) as ONE launch
+  bool can_fuse_fcn(const Conv& c1, const Conv& c2) const {
+    return use_f16 && c1.wpack16 && c2.wpack16 && c1.taps == 9 && c2.taps == 1 && c1.cout == 64 && c2.cout == 64 &&
+           c2.nsrc == 1 && c2.src_n[0] == 64;
+  }
+
   void run_conv(const Conv& cv, std::vector<View> srcs, int H, int W, View out, View res1 = mkview(nullptr, 0, 0, 0),
-                float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f) {
+                float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f, const Conv* fuse2 = nullptr) {
     if (rc != HCF_OK) return;
     if ((int)srcs.size() != cv.nsrc) { fail(HCF_ERR_STATE, "internal: conv source count"); return; }
     ConvArgs a;
@@ -536,7 +542,7 @@ struct hcf_engine {
       }
       prof_events[prof_used].taps = cv.taps;
       prof_events[prof_used].nt = cv.npad / 32;
-      prof_events[prof_used].flops = cv.flops_per_pixel * (double)B_ * H * W;
+      prof_events[prof_used].flops = (cv.flops_per_pixel + (fuse2 ? fuse2->flops_per_pixel : 0.0)) * (double)B_ * H * W;
       {   // algorithmic HBM bytes: every source window read once, output written once, residuals read once, weights once
         double px_bytes = 4.0 * cv.cout * (1 + (res1.p ? 1 : 0) + (res2.p ? 1 : 0));
         for (int i = 0; i < cv.nsrc; ++i) px_bytes += 4.0 * cv.src_n[i] / (double)(1 << (2 * srcs[i].up));
@@ -548,6 +554,9 @@ struct hcf_engine {
     if (use_f16 && cv.wpack16 && cv.taps == 9) {
       a.wpack = cv.wpack16;
       a.ovf = ovf_flag;
+      if (fuse2) {
+        a.w2 = fuse2->wpack16; a.bias2 = fuse2->bias; a.scale2 = fuse2->scale; a.act2 = fuse2->act;
+      }
       r = launch_conv_f16x3(a, cv.taps, st);
     } else {
       r = launch_conv(a, cv.taps, st);
@@ -580,8 +589,13 @@ struct hcf_engine {
       in.push_back(*u);
     }
     if (s.fcn) {
-      run_conv(s.c[0], in, H, W, sc.h1.v(0, s.hid));
-      run_conv(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
+      if (can_fuse_fcn(s.c[0], s.c[1])) {
+        const View none = mkview(nullptr, 0, 0, 0);
+        run_conv(s.c[0], in, H, W, sc.h2.v(0, s.hid), none, 0.f, none, 0.f, &s.c[1]);
+      } else {
+        run_conv(s.c[0], in, H, W, sc.h1.v(0, s.hid));
+        run_conv(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
+      }
       run_conv(s.c[2], {sc.h2.v(0, s.hid)}, H, W, sc.hout.v(0, s.f_out));
     } else {
       for (int i = 0; i < 5; ++i) {
