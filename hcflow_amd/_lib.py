@@ -9,7 +9,7 @@ import os
 from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhcflow_hip.so")
+LIB_PATH = os.environ.get("HCFLOW_LIB", os.path.join(_HERE, "libhcflow_hip.so"))   # override: kernel experiments
 
 HCF_OK = 0
 ERR_NAMES = {-1: "HCF_ERR_ARG", -2: "HCF_ERR_HIP", -3: "HCF_ERR_STATE", -4: "HCF_ERR_KEY",

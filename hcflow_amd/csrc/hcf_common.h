@@ -55,6 +55,9 @@ struct ConvArgs {
   // f16x3 kernel, optional fused second layer (FCN conv2: 1x1, 64 -> 64): out = act2((W2 * act(layer1) + bias2) * scale2)
   const float* w2;         // f16x3 pack of the 1x1 weights (taps = 1) or nullptr
   const float* bias2; const float* scale2; int act2;
+  // f16x3 kernel, optional fused inverse flow-step tail (tC > 0): z <- actnorm^-1(W^-1 coupling^-1(z, h = this conv))
+  View tz; View tzo; const float* tmat; const float* tbias; const float* tmul; int tC, tns, tmode;
+  const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
   int stagger;             // unused
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };

@@ -35,6 +35,7 @@
 //     inf / NaN; the epilogue tests the raw accumulators and raises a device flag, upon which the engine
 //     re-runs the pass on the exact fp32 kernel (hcf_conv.hip).
 #include "hcf_common.h"
+#include "hcf_step_math.h"
 
 namespace hcf {
 
@@ -49,11 +50,20 @@ typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 
 int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N: start stagger (x 2048 clocks) between co-resident blocks
 
+#ifndef HCF_DBG_NOZPAGE
+#define HCF_DBG_NOZPAGE 0
+#endif
+#ifndef HCF_DBG_NOINTER
+#define HCF_DBG_NOINTER 0
+#endif
+#ifndef HCF_ABL
+#define HCF_ABL 0     // timing ablations, build with -DHCF_ABL=bits: 1 no weight staging, 2 no activation staging, 4 no barriers
+#endif
+
 namespace f16x3 {
 
 constexpr int KC = 16;
-constexpr int TH = 8;
-constexpr int TW = 32;
+constexpr int TW = 32;             // tile width in pixels = MFMA M (one image row segment per fragment)
 constexpr int REC = 80;          // bytes per halo pixel in LDS
 constexpr float SPLIT = 2048.f;  // 2^11
 
@@ -75,23 +85,42 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // FUSE2 (NTB = 2 only): the block also applies the FCN's second layer (Basic.py:443-444), a 1x1 conv 64 -> 64 with
 // ActNorm + ReLU, to its own output tile before storing: relu(AN1(conv3x3)) goes to LDS as split f16, 48 more MFMAs
 // per wave form the 64 x 64 GEMM, and only H2 is written to HBM (the stand-alone 1x1 kernel was HBM-bound).
-template <int NTB, bool VEC, bool UP, bool FUSE2 = false>
-__global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(const ConvArgs a) {
+// TAILC > 0 (Conv2dZeros at the end of a coupling net, inverse pass): the block finishes the flow step itself
+// (FlowStep.py:53-64): its h tile goes to LDS (pixel-major), then one thread per pixel applies coupling^-1, the
+// invertible 1x1 conv and ActNorm^-1 to z in place. TAILC = register-array bucket for z (8 / 12 / 24 / 48).
+// TH = tile height (8: 4 waves / 256 threads; 16: 8 waves / 512 threads). The taller tile halves the weight
+// staging per pixel, trims the halo overhead (1.33x -> 1.2x) and halves the staging registers per thread.
+template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8>
+__global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+  static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
+  static_assert(TH == 8 || (!FUSE2 && TAILC == 0), "fused epilogues are sized for the 8-row tile");
+  constexpr int NTHR = 32 * TH;
+  // Interleaving the next chunk's split into the last taps is worth ~10 % on the plain kernels. In the fused-tail
+  // variants it produced wrong pixels whenever several blocks shared a CU (B >= 2 at 160^2; cause not understood,
+  // ISA and resource usage look sane) -> kept off there; tests/test_gpu_f16x3.py::test_large_grid_* guards this.
+  constexpr bool INTERLEAVE = (TAILC == 0) && !HCF_DBG_NOINTER;
   static_assert(!FUSE2 || NTB == 2, "the fused 1x1 layer needs all 64 channels of the tile in one block");
   constexpr int TAPS = 9, PAD = 1;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   constexpr int NLOAD = HP * (KC / 4);
-  constexpr int NSLOT = (NLOAD + 255) / 256;        // float4 staging slots per thread (A)
+  constexpr int NSLOT = (NLOAD + NTHR - 1) / NTHR;   // float4 staging slots per thread (A)
   constexpr int NPAD = NTB * 32;
   constexpr int MT = 2 * NTB;                       // 32-pixel row tiles per wave
   constexpr int A_BYTES = HP * REC;
   constexpr int BHALF = NPAD * 16;                  // bytes of one (tap, plane, k-half): n x 8 halves
   constexpr int B_BYTES = TAPS * 2 * 2 * BHALF;     // per chunk
   constexpr int BV = B_BYTES / 16;                  // float4 units
-  constexpr int BSLOT = (BV + 255) / 256;
+  constexpr int BSLOT = (BV + NTHR - 1) / NTHR;
   constexpr int F2_BYTES = FUSE2 ? (TH * TW) * 4 * 64 : 0;      // [256 px][4 k-chunks][16 hi | 16 lo]
-  constexpr int LDS_BYTES = (A_BYTES + B_BYTES > F2_BYTES) ? (A_BYTES + B_BYTES) : F2_BYTES;
+  constexpr int HCS = (NTB == 1) ? 33 : 49;                      // odd row stride of the h tile (floats): conflict-free
+  constexpr int T_BYTES = TAILC ? (TH * TW) * HCS * 4 : 0;
+  constexpr int LDS_MAIN = A_BYTES + B_BYTES;
+  constexpr int LDS_BYTES = (LDS_MAIN > F2_BYTES ? (LDS_MAIN > T_BYTES ? LDS_MAIN : T_BYTES) : (F2_BYTES > T_BYTES ? F2_BYTES : T_BYTES));
+#ifdef HCF_DBG_BIGLDS
+  __shared__ __attribute__((aligned(16))) char lds[TAILC ? 100000 : LDS_BYTES];
+#else
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+#endif
   char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   unsigned okmask = 0;
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    const int q = tid + 256 * s;
+    const int q = tid + NTHR * s;
     const int hp = min(q >> 2, HP - 1);
     const int hy = hp / HW, hx = hp - hy * HW;
     const int y = y0 + hy - PAD, x = x0 + hx - PAD;
@@ -136,6 +165,7 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   const int n0 = __builtin_amdgcn_readfirstlane(a.src[0].n), n1 = __builtin_amdgcn_readfirstlane(a.src[1].n),
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
   const gf4ptr wq = (gf4ptr)uniform_ptr(a.wpack) + tid;   // this thread's float4 lane of the weight stream
+  const gfptr zpage = uniform_ptr(a.zeros);
 
   int stg_valid = 0;       // valid channels (0..4+) of this thread's 4-channel unit in the staged chunk
   f32x4 stg[NSLOT];        // next chunk's activations: fp32 after the load, (hi, lo) f16 pairs after the split
@@ -159,6 +189,7 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
         pidx = (b * Hs + y) * Ws + x;                                                             \
       }                                                                                           \
       gfptr p = sp + (unsigned)(pidx * css); /* launcher guarantees < 2^31 elements per tensor */ \
+      if (!HCF_DBG_NOZPAGE) p = ((okmask >> s) & 1u) ? p : zpage; /* conv zero padding: read a page of zeros */ \
       f32x4 v;                                                                                    \
       if (VEC) {                                                                                  \
         v = *(gf4ptr)(p);                                                                         \
@@ -168,35 +199,40 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
       stg[s] = v; /* RAW load result: nothing here may consume it, or the wave waits for HBM now */ \
     }                                                                                             \
     stg_valid = valid;                                                                            \
-    _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
-      const int q = tid + 256 * s;                                                                \
-      stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? 256 * s : 0)];                               \
-    }                                                                                             \
-  }
-  // split in registers (VALU only): stg[s] <- {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves
-#define HCF_STAGE_SPLIT()                                                                         \
-  {                                                                                               \
-    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
-      f32x4 v = stg[s];                                                                           \
-      const bool ok = (okmask >> s) & 1u; /* zero padding of the conv + channel tail of the window */ \
-      v.x = (ok && stg_valid > 0) ? v.x : 0.f;                                                    \
-      v.y = (ok && stg_valid > 1) ? v.y : 0.f;                                                    \
-      v.z = (ok && stg_valid > 2) ? v.z : 0.f;                                                    \
-      v.w = (ok && stg_valid > 3) ? v.w : 0.f;                                                    \
-      union { f16x4 h[2]; f32x4 f; } u_;                                                          \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-        const _Float16 h = (_Float16)v[e];                                                        \
-        u_.h[0][e] = h;                                                                           \
-        u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                 \
+    if (!(HCF_ABL & 1)) {                                                                         \
+      _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                         \
+        const int q = tid + NTHR * s;                                                             \
+        stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? NTHR * s : 0)];                            \
       }                                                                                           \
-      stg[s] = u_.f;                                                                              \
     }                                                                                             \
   }
+  // split one staged slot in registers (VALU only): stg[s] <- {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves.
+  // Only the channel tail of a window (valid < 4: C = 3, 6, 10, 21 ...) needs masking; image borders read the zero page.
+#define HCF_SPLIT_SLOT(S)                                                                         \
+  {                                                                                               \
+    f32x4 v = stg[S];                                                                             \
+    if (HCF_DBG_NOZPAGE && !((okmask >> (S)) & 1u)) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; } \
+    if (stg_valid < 4) {                                                                          \
+      v.x = (stg_valid > 0) ? v.x : 0.f;                                                          \
+      v.y = (stg_valid > 1) ? v.y : 0.f;                                                          \
+      v.z = (stg_valid > 2) ? v.z : 0.f;                                                          \
+      v.w = 0.f;                                                                                  \
+    }                                                                                             \
+    union { f16x4 h[2]; f32x4 f; } u_;                                                            \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+      const _Float16 h = (_Float16)v[e];                                                          \
+      u_.h[0][e] = h;                                                                             \
+      u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                   \
+    }                                                                                             \
+    stg[S] = u_.f;                                                                                \
+  }
+#define HCF_STAGE_SPLIT()                                                                         \
+  { _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) HCF_SPLIT_SLOT(s) }
   // only LDS writes: two 8-byte pieces per activation slot (hi half-plane, lo half-plane), 16 B per weight slot
 #define HCF_STAGE_WRITE()                                                                         \
   {                                                                                               \
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
-      const int q = tid + 256 * s;                                                                \
+      const int q = tid + NTHR * s;                                                               \
       if (q < NLOAD) {                                                                            \
         char* rec = lds + (q >> 2) * REC + (q & 3) * 8;                                           \
         union { f16x4 h[2]; f32x4 f; } u_;                                                        \
@@ -206,7 +242,7 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
-      const int q = tid + 256 * s;                                                                \
+      const int q = tid + NTHR * s;                                                               \
       if (q < BV) *reinterpret_cast<f32x4*>(ldsB + q * 16) = stb[s];                              \
     }                                                                                             \
   }
@@ -229,7 +265,7 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   const int nchunk = a.nchunk;
   for (int c = 0; c < nchunk; ++c) {
     const bool more = (c + 1 < nchunk);
-    if (more) HCF_STAGE_LOAD(c + 1);               // global loads fly under this chunk's MFMAs
+    if (more && !(HCF_ABL & 2)) HCF_STAGE_LOAD(c + 1);   // global loads fly under this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -244,6 +280,14 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
         ahi[m] = *reinterpret_cast<const f16x8*>(rec);
         alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
       }
+      // the split of the NEXT chunk's staged slots rides in the MFMA shadow of the last taps (its loads were
+      // issued a whole chunk of MFMAs earlier); two slots per tap
+      if (INTERLEAVE && more && !(HCF_ABL & 2) && t >= TAPS - (NSLOT + 1) / 2) {
+        constexpr int dummy = 0; (void)dummy;
+        const int s0 = 2 * (t - (TAPS - (NSLOT + 1) / 2));
+        if (s0 < NSLOT) HCF_SPLIT_SLOT(s0)
+        if (s0 + 1 < NSLOT) HCF_SPLIT_SLOT(s0 + 1)
+      }
       // term-major order: consecutive MFMAs hit different accumulators (MT independent chains)
 #pragma unroll
       for (int m = 0; m < MT; ++m)   // a_hi * (b_hi 2^11)
@@ -256,10 +300,10 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
     }
     if (!more) break;
-    HCF_STAGE_SPLIT();                             // VALU only, before the barrier
-    __syncthreads();                               // every wave has finished reading this chunk
-    HCF_STAGE_WRITE();
-    __syncthreads();
+    if (!INTERLEAVE) HCF_STAGE_SPLIT();            // (otherwise the split already ran inside the last taps)
+    if (!(HCF_ABL & 4)) __syncthreads();           // every wave has finished reading this chunk
+    if (!(HCF_ABL & 2)) HCF_STAGE_WRITE();
+    if (!(HCF_ABL & 4)) __syncthreads();
   }
 #undef HCF_STAGE_LOAD
 #undef HCF_STAGE_SPLIT
@@ -338,6 +382,32 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
     if (lane == 0) atomicOr(a.ovf, 1);
   }
 
+  if constexpr (TAILC > 0) {
+    float* hl = reinterpret_cast<float*>(lds);
+    const float bias_t = a.bias[oc], scale_t = a.scale[oc];
+    __syncthreads();                                 // every wave is done with the staging buffers
+    if (ocok) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
+          hl[px * HCS + oc] = (acc[m][r] * UNSPLIT + bias_t) * scale_t;       // Conv2dZeros: no activation
+        }
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    const int y = y0 + ty, x = x0 + tx;
+    if (y < H && x < W) {
+      const size_t pix = (size_t)((size_t)b * H + y) * W + x;
+      float z[TAILC], yv[TAILC];
+      load_pixel<TAILC>(a.tz, pix, a.tC, z);
+      step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
+      store_pixel<TAILC>(a.tzo, pix, a.tC, yv);
+    }
+    return;
+  }
+
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
   const int act = FUSE2 ? a.act2 : a.act;
 #pragma unroll
@@ -359,9 +429,14 @@ __global__ __launch_bounds__(256, (NTB == 1) ? 3 : 2) void conv_f16x3_kernel(con
   }
 }
 
+int g_f16x3_tall = 0;   // 16-row tile variants measured no better than the 8-row tile (profiles/r01_f16x3_notes.md); bit0 NTB=1, bit1 NTB=2
+
 template <int NTB>
 static int launch_t(const ConvArgs& a, hipStream_t st) {
-  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const bool plain = !(a.tC > 0) && !a.w2;
+  const bool tall = plain && (((g_f16x3_tall ^ g_f16x3_ablation) >> (NTB - 1)) & 1) && a.H >= 16;   // --ablate 1/2/3 turns it off
+  const int THr = tall ? 16 : 8;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + THr - 1) / THr;
   const long long nblk = (long long)a.B * tiles_x * tiles_y;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;
   bool vec = true;
@@ -374,7 +449,18 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     // 32-bit element offsets inside the kernel
     if ((long long)a.B * (a.H >> a.src[i].up) * (a.W >> a.src[i].up) * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
   }
-  if (a.w2) {      // fused FCN conv1 + conv2
+  if (a.tC > 0) {  // fused inverse flow-step tail
+    if (!vec || b.any_up || a.w2 || a.res1.p || a.res2.p || a.act != ACT_NONE || a.out.n > ((NTB == 1) ? 32 : 48)) return HCF_ERR_ARG;
+    const int cm = step_cmax(a.tC);
+    if constexpr (NTB == 1) {
+      if (cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else if (cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else if (cm == 24) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 24>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else return HCF_ERR_UNSUPPORTED;
+    } else {
+      return HCF_ERR_UNSUPPORTED;     // 45/48-channel steps (x8 level 2) keep the stand-alone tail kernel
+    }
+  } else if (a.w2) {      // fused FCN conv1 + conv2
     if constexpr (NTB == 2) {
       if (!vec || a.out.n != 64 || !a.bias2 || !a.scale2 || a.res1.p || a.res2.p) return HCF_ERR_ARG;
       if (b.any_up)
@@ -384,7 +470,13 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     } else {
       return HCF_ERR_ARG;
     }
-  } else if (vec && !b.any_up)
+  } else if (tall && vec && !b.any_up)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
+  else if (tall && vec)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
+  else if (tall)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
+  else if (vec && !b.any_up)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else if (vec)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);

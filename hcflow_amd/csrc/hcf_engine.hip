@@ -8,6 +8,7 @@
 //   FCN / DenseBlock / RRDB     Basic.py:329-447
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -173,7 +174,7 @@ struct hcf_engine {
   // numerics: PREC_EXACT = fp32 MFMA everywhere; PREC_F16X3 = fp32-equivalent split on f16 MFMA
   int precision = PREC_EXACT;
   bool use_f16 = false;        // precision of the pass being enqueued
-  int* ovf_flag = nullptr;     // device
+  int* ovf_flag = nullptr;     // device: [0] = range flag, bytes 64..191 = zero page for the f16x3 kernel
   int64_t n_fallbacks = 0;
 
   int fail(int code, const std::string& msg) {
@@ -512,12 +513,14 @@ struct hcf_engine {
 
   // f16x3 mode can run FCN conv1 (3x3 -> 64) and conv2 (1x1 64 -> 64) as ONE launch
   bool can_fuse_fcn(const Conv& c1, const Conv& c2) const {
+    if (getenv("HCF_NO_FUSE_FCN")) return false;      // debugging aid
     return use_f16 && c1.wpack16 && c2.wpack16 && c1.taps == 9 && c2.taps == 1 && c1.cout == 64 && c2.cout == 64 &&
            c2.nsrc == 1 && c2.src_n[0] == 64;
   }
 
   void run_conv(const Conv& cv, std::vector<View> srcs, int H, int W, View out, View res1 = mkview(nullptr, 0, 0, 0),
-                float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f, const Conv* fuse2 = nullptr) {
+                float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f, const Conv* fuse2 = nullptr,
+                const StepArgs* tail = nullptr) {
     if (rc != HCF_OK) return;
     if ((int)srcs.size() != cv.nsrc) { fail(HCF_ERR_STATE, "internal: conv source count"); return; }
     ConvArgs a;
@@ -554,8 +557,13 @@ struct hcf_engine {
     if (use_f16 && cv.wpack16 && cv.taps == 9) {
       a.wpack = cv.wpack16;
       a.ovf = ovf_flag;
+      a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
       if (fuse2) {
         a.w2 = fuse2->wpack16; a.bias2 = fuse2->bias; a.scale2 = fuse2->scale; a.act2 = fuse2->act;
+      }
+      if (tail) {
+        a.tz = tail->z; a.tzo = tail->out; a.tmat = tail->mat; a.tbias = tail->an_bias; a.tmul = tail->an_mul;
+        a.tC = tail->C; a.tns = tail->ns; a.tmode = tail->mode;
       }
       r = launch_conv_f16x3(a, cv.taps, st);
     } else {
@@ -581,7 +589,15 @@ struct hcf_engine {
   };
 
   // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
-  void run_coupling_net(const Step& s, View z1, const View* u, int H, int W, Scratch& sc) {
+  // f16x3 mode: the last conv of an FCN coupling net can finish the inverse flow step in its epilogue
+  bool can_fuse_tail(const Step& s) const {
+    if (getenv("HCF_NO_FUSE_TAIL")) return false;     // debugging aid
+    const Conv& c = s.c[2];
+    const int lim = getenv("HCF_TAIL_CMAX") ? atoi(getenv("HCF_TAIL_CMAX")) : 24;
+    return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= lim;   // the 48-channel variant spills
+  }
+
+  void run_coupling_net(const Step& s, View z1, const View* u, int H, int W, Scratch& sc, const StepArgs* tail = nullptr) {
     std::vector<View> in;
     in.push_back(z1);
     if (s.cond > 0) {
@@ -596,7 +612,10 @@ struct hcf_engine {
         run_conv(s.c[0], in, H, W, sc.h1.v(0, s.hid));
         run_conv(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
       }
-      run_conv(s.c[2], {sc.h2.v(0, s.hid)}, H, W, sc.hout.v(0, s.f_out));
+      {
+        const View none = mkview(nullptr, 0, 0, 0);
+        run_conv(s.c[2], {sc.h2.v(0, s.hid)}, H, W, sc.hout.v(0, s.f_out), none, 0.f, none, 0.f, nullptr, tail);
+      }
     } else {
       for (int i = 0; i < 5; ++i) {
         std::vector<View> srcs = in;
@@ -614,12 +633,23 @@ struct hcf_engine {
 
   // FlowStep.reverse_flow (FlowStep.py:53-64), in place on z
   void run_step_inverse(const Step& s, const Buf& z, const View* u, int H, int W, Scratch& sc) {
-    run_coupling_net(s, step_z1(s, z), u, H, W, sc);
     StepArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B_; a.H = H; a.W = W; a.C = s.C; a.ns = s.ns; a.mode = s.mode;
     a.z = z.all(); a.h = sc.hout.v(0, s.f_out); a.out = z.all();
     a.mat = s.has_mat ? s.mat_inv : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_inv;
+    if (can_fuse_tail(s)) {
+      if (getenv("HCF_TAIL_OOP")) {                             // debugging aid: out-of-place tail + copy back
+        Buf tmp = alloc(B_, H, W, s.C);
+        a.out = tmp.all();
+        run_coupling_net(s, step_z1(s, z), u, H, W, sc, &a);
+        HCF_LAUNCH(launch_copy_view(tmp.all(), z.all(), B_, H, W, st));
+        return;
+      }
+      run_coupling_net(s, step_z1(s, z), u, H, W, sc, &a);      // conv3's epilogue finishes the step
+      return;
+    }
+    run_coupling_net(s, step_z1(s, z), u, H, W, sc);
     HCF_LAUNCH(launch_step_tail_inv(a, st));
   }
 
@@ -890,6 +920,7 @@ struct hcf_engine {
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
     st = stream;
+    use_f16 = (precision == PREC_F16X3);      // also during the sizing run: fusion decisions must not differ
     arena.dry = true;
     arena.peak = 0;
     body();
@@ -898,9 +929,9 @@ struct hcf_engine {
     if (ensure_arena(arena.peak) != HCF_OK) return rc;
     use_f16 = (precision == PREC_F16X3);
     if (use_f16) {
-      if (!ovf_flag && hipMalloc((void**)&ovf_flag, sizeof(int)) != hipSuccess)
+      if (!ovf_flag && hipMalloc((void**)&ovf_flag, 256) != hipSuccess)
         return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
-      if (hipMemsetAsync(ovf_flag, 0, sizeof(int), st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+      if (hipMemsetAsync(ovf_flag, 0, 256, st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
     }
     body();
     if (use_f16 && rc == HCF_OK && !(pass_flags & HCF_FLAG_NO_RANGE_CHECK)) {

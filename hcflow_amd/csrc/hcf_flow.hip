@@ -4,10 +4,9 @@
 // matrices are wave-uniform (scalar loads, SGPR operands of v_fma). Per-sample log-det sums use
 // wave shuffles -> LDS -> one partial per block (deterministic; reduced later in double).
 #include "hcf_common.h"
+#include "hcf_step_math.h"
 
 namespace hcf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -26,62 +25,6 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return r;
 }
 
-__device__ __forceinline__ float logscale_of(float s) {
-  // 0.318 * atan(2 * scale)   (AffineCouplings.py:53,83)
-  return 0.318f * atanf(2.f * s);
-}
-
-template <int CMAX>
-__device__ __forceinline__ void load_pixel(const View& v, size_t pix, int C, float (&z)[CMAX]) {
-  const float* p = v.p + pix * v.cs + v.c0;
-  if (((v.cs | v.c0) & 3) == 0) {
-#pragma unroll
-    for (int c4 = 0; c4 < CMAX / 4; ++c4) {
-      if (4 * c4 < C) {                      // cs = roundup4(C): the whole float4 is inside the pixel
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * c4);
-        z[4 * c4 + 0] = t.x;
-        z[4 * c4 + 1] = (4 * c4 + 1 < C) ? t.y : 0.f;
-        z[4 * c4 + 2] = (4 * c4 + 2 < C) ? t.z : 0.f;
-        z[4 * c4 + 3] = (4 * c4 + 3 < C) ? t.w : 0.f;
-      } else {
-        z[4 * c4 + 0] = 0.f; z[4 * c4 + 1] = 0.f; z[4 * c4 + 2] = 0.f; z[4 * c4 + 3] = 0.f;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? p[c] : 0.f;
-  }
-}
-
-template <int CMAX>
-__device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, const float (&z)[CMAX]) {
-  float* p = v.p + pix * v.cs + v.c0;
-  if (((v.cs | v.c0) & 3) == 0 && (C & 3) == 0) {
-#pragma unroll
-    for (int c4 = 0; c4 < CMAX / 4; ++c4)
-      if (4 * c4 < C) {
-        f32x4 t = {z[4 * c4], z[4 * c4 + 1], z[4 * c4 + 2], z[4 * c4 + 3]};
-        *reinterpret_cast<f32x4*>(p + 4 * c4) = t;
-      }
-  } else {
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) p[c] = z[c];
-  }
-}
-
-// y = M z with M row-major [CMAX][CMAX] (host pads rows/cols beyond C with zeros)
-template <int CMAX>
-__device__ __forceinline__ void matvec(const float* __restrict__ M, const float (&z)[CMAX], float (&y)[CMAX]) {
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c) {
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < CMAX; ++k) acc = fmaf(M[c * CMAX + k], z[k], acc);
-    y[c] = acc;
-  }
-}
-
 // ---- inverse flow step tail: coupling^-1 -> W^-1 -> actnorm^-1  (FlowStep.py:53-64) -----------
 template <int CMAX>
 __global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
@@ -92,31 +35,8 @@ __global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
   float z[CMAX];
   load_pixel<CMAX>(a.z, pix, a.C, z);
   const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
-  if (a.mode == CPL_AFFINE) {
-    // z2 = z2 * exp(-logscale) - shift, (shift, scale) = h[0::2], h[1::2]  (AffineCouplings.py:65-87)
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-      if (c >= a.ns && c < a.C) {
-        const int j = c - a.ns;
-        const float shift = hp[2 * j], scale = hp[2 * j + 1];
-        z[c] = z[c] * expf(-logscale_of(scale)) - shift;
-      }
-    }
-  } else {
-    // AffineCoupling3shift, LRvsothers=False: z[:3] -= f(z[3:])  (AffineCouplings.py:150-153)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) z[c] = z[c] - hp[c];
-  }
   float y[CMAX];
-  if (a.mat) {
-    matvec<CMAX>(a.mat, z, y);
-  } else {
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) y[c] = z[c];
-  }
-  // actnorm reverse: x * exp(-logs) - bias  (ActNorms.py:54,66)
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c) y[c] = y[c] * a.an_mul[c] - a.an_bias[c];
+  step_tail_inverse_pixel<CMAX>(z, hp, a.C, a.ns, a.mode, a.mat, a.an_bias, a.an_mul, y);
   store_pixel<CMAX>(a.out, pix, a.C, y);
 }
 

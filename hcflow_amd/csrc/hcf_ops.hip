@@ -47,8 +47,9 @@ static int pack_and_launch(Tmp& t, ConvArgs& a, const float* w, int cin, int cou
   const bool f16 = (g_op_precision == PREC_F16X3) && cout <= 64 && k == 3;
   if (f16) {
     if (!pack_conv_weights_f16x3(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad)) return HCF_ERR_UNSUPPORTED;
-    a.ovf = (int*)t.dev(1);
-    if (a.ovf && hipMemsetAsync(a.ovf, 0, sizeof(int), st) != hipSuccess) return HCF_ERR_HIP;
+    a.ovf = (int*)t.dev(64);
+    if (a.ovf && hipMemsetAsync(a.ovf, 0, 256, st) != hipSuccess) return HCF_ERR_HIP;
+    a.zeros = reinterpret_cast<const float*>(a.ovf) + 16;
   } else {
     pack_conv_weights(w, cin, cout, k * k, srcs, n_src, pk, nchunk, npad);
   }

@@ -1,0 +1,102 @@
+// Per-pixel flow-step arithmetic shared by the stand-alone step kernels (hcf_flow.hip) and the fused conv
+// epilogue (hcf_conv_f16x3.hip): a pixel's channel vector lives in registers (CMAX-sized arrays, compile-time
+// indexing only), the C x C matrix is wave-uniform.
+#pragma once
+#include "hcf_common.h"
+
+namespace hcf {
+
+typedef float step_f32x4 __attribute__((ext_vector_type(4)));
+#define f32x4_step step_f32x4
+
+__device__ __forceinline__ float logscale_of(float s) {
+  // 0.318 * atan(2 * scale)   (AffineCouplings.py:53,83)
+  return 0.318f * atanf(2.f * s);
+}
+
+template <int CMAX>
+__device__ __forceinline__ void load_pixel(const View& v, size_t pix, int C, float (&z)[CMAX]) {
+  const float* p = v.p + pix * v.cs + v.c0;
+  if (((v.cs | v.c0) & 3) == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < CMAX / 4; ++c4) {
+      if (4 * c4 < C) {                      // cs = roundup4(C): the whole float4 is inside the pixel
+        const step_f32x4 t = *reinterpret_cast<const step_f32x4*>(p + 4 * c4);
+        z[4 * c4 + 0] = t.x;
+        z[4 * c4 + 1] = (4 * c4 + 1 < C) ? t.y : 0.f;
+        z[4 * c4 + 2] = (4 * c4 + 2 < C) ? t.z : 0.f;
+        z[4 * c4 + 3] = (4 * c4 + 3 < C) ? t.w : 0.f;
+      } else {
+        z[4 * c4 + 0] = 0.f; z[4 * c4 + 1] = 0.f; z[4 * c4 + 2] = 0.f; z[4 * c4 + 3] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) z[c] = (c < C) ? p[c] : 0.f;
+  }
+}
+
+template <int CMAX>
+__device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, const float (&z)[CMAX]) {
+  float* p = v.p + pix * v.cs + v.c0;
+  if (((v.cs | v.c0) & 3) == 0 && (C & 3) == 0) {
+#pragma unroll
+    for (int c4 = 0; c4 < CMAX / 4; ++c4)
+      if (4 * c4 < C) {
+        step_f32x4 t = {z[4 * c4], z[4 * c4 + 1], z[4 * c4 + 2], z[4 * c4 + 3]};
+        *reinterpret_cast<step_f32x4*>(p + 4 * c4) = t;
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) p[c] = z[c];
+  }
+}
+
+// y = M z with M row-major [CMAX][CMAX] (host pads rows/cols beyond C with zeros)
+template <int CMAX>
+__device__ __forceinline__ void matvec(const float* __restrict__ M, const float (&z)[CMAX], float (&y)[CMAX]) {
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) acc = fmaf(M[c * CMAX + k], z[k], acc);
+    y[c] = acc;
+  }
+}
+
+
+// FlowStep.reverse_flow after the coupling network (FlowStep.py:53-64): coupling^-1 -> W^-1 -> actnorm^-1 on one
+// pixel. `hp` points at the pixel's coupling-net output (global memory or LDS), stride 1.
+template <int CMAX, typename HPtr>
+__device__ __forceinline__ void step_tail_inverse_pixel(float (&z)[CMAX], HPtr hp, int C, int ns, int mode,
+                                                        const float* __restrict__ mat,
+                                                        const float* __restrict__ an_bias,
+                                                        const float* __restrict__ an_mul, float (&y)[CMAX]) {
+  if (mode == CPL_AFFINE) {
+    // z2 = z2 * exp(-logscale) - shift, (shift, scale) = h[0::2], h[1::2]  (AffineCouplings.py:65-87)
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c >= ns && c < C) {
+        const int j = c - ns;
+        const float shift = hp[2 * j], scale = hp[2 * j + 1];
+        z[c] = z[c] * expf(-logscale_of(scale)) - shift;
+      }
+    }
+  } else {
+    // AffineCoupling3shift, LRvsothers=False: z[:3] -= f(z[3:])  (AffineCouplings.py:150-153)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[c] = z[c] - hp[c];
+  }
+  if (mat) {
+    matvec<CMAX>(mat, z, y);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) y[c] = z[c];
+  }
+  // actnorm reverse: x * exp(-logs) - bias  (ActNorms.py:54,66)
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) y[c] = y[c] * an_mul[c] - an_bias[c];
+}
+
+}  // namespace hcf

@@ -123,3 +123,28 @@ def test_f16x3_vs_exact_full_size_and_fallback():
             assert torch.allclose(fb, eb, rtol=0, atol=0, equal_nan=True)      # bit-identical re-run
         finally:
             net.set_precision("exact")
+
+
+@pytest.mark.parametrize("B", [4])
+def test_large_grid_f16x3_matches_exact_and_is_deterministic(B):
+    """Grids with several blocks per CU (B=4 at 160x160: 1 600 / 6 400 blocks): the f16x3 path, with its fused
+    epilogues, must agree with the exact kernels and be bit-identical from run to run (a race between co-resident
+    blocks once slipped through every small-size test)."""
+    cfg = preset("SR_4X_tiny")
+    p = cached_params("SR_4X_tiny", 11)
+    net = build_net(cfg, p)
+    g = torch.Generator().manual_seed(21)
+    lr = torch.rand(B, 3, 160, 160, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, 160, 160)]
+    with torch.no_grad():
+        ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+        net.set_precision("f16x3")
+        try:
+            runs = [net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False) for _ in range(3)]
+        finally:
+            net.set_precision("exact")
+    assert maxdiff(runs[0], ex) <= 2e-5 * max(1.0, float(ex.abs().max()))
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    with torch.no_grad():
+        ex2 = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+    assert torch.equal(ex, ex2)
