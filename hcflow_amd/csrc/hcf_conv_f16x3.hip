@@ -56,6 +56,9 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N: start stagger (x 
 #ifndef HCF_DBG_NOINTER
 #define HCF_DBG_NOINTER 0
 #endif
+#ifndef HCF_SETPRIO
+#define HCF_SETPRIO 1
+#endif
 #ifndef HCF_ABL
 #define HCF_ABL 0     // timing ablations, build with -DHCF_ABL=bits: 1 no weight staging, 2 no activation staging, 4 no barriers
 #endif
@@ -267,6 +270,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     const bool more = (c + 1 < nchunk);
     if (more && !(HCF_ABL & 2)) HCF_STAGE_LOAD(c + 1);   // global loads fly under this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
+#if HCF_SETPRIO
+    __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD
+#endif
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int dy = t / 3, dx = t % 3;
@@ -299,6 +305,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
     }
+#if HCF_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (!more) break;
     if (!INTERLEAVE) HCF_STAGE_SPLIT();            // (otherwise the split already ran inside the last taps)
     if (!(HCF_ABL & 4)) __syncthreads();           // every wave has finished reading this chunk
