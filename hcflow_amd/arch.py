@@ -225,7 +225,8 @@ class FlowNet(nn.Module):
             C = ns
             self.output_shapes.append([-1, C, H, W])
         self.H, self.W = H, W
-        print('shapes:', self.output_shapes)      # FlowNet_SR_x4.py:71
+        # (the reference prints this list at construction, FlowNet_SR_x4.py:71; kept as an attribute only so
+        #  that stdout stays clean for tools that parse it, e.g. bench.py's single JSON line)
 
 
 # ------------------------------------------------------------------ engine-backed top modules

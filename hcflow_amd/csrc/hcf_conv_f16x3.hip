@@ -35,6 +35,7 @@
 //     inf / NaN; the epilogue tests the raw accumulators and raises a device flag, upon which the engine
 //     re-runs the pass on the exact fp32 kernel (hcf_conv.hip).
 #include "hcf_common.h"
+#include <cstdlib>
 #include "hcf_step_math.h"
 
 namespace hcf {
@@ -58,6 +59,12 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N: start stagger (x 
 #endif
 #ifndef HCF_SETPRIO
 #define HCF_SETPRIO 1
+#endif
+#ifndef HCF_DXMAJOR
+#define HCF_DXMAJOR 0   // 1: dx-major sliding-window tap loop (fewer LDS reads, same speed: profiles/r01_f16x3_notes.md v9)
+#endif
+#ifndef HCF_DX_PIN
+#define HCF_DX_PIN 2
 #endif
 #ifndef HCF_ABL
 #define HCF_ABL 0     // timing ablations, build with -DHCF_ABL=bits: 1 no weight staging, 2 no activation staging, 4 no barriers
@@ -98,9 +105,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
   static_assert(TH == 8 || (!FUSE2 && TAILC == 0), "fused epilogues are sized for the 8-row tile");
   constexpr int NTHR = 32 * TH;
-  // Interleaving the next chunk's split into the last taps is worth ~10 % on the plain kernels. In the fused-tail
-  // variants it produced wrong pixels whenever several blocks shared a CU (B >= 2 at 160^2; cause not understood,
-  // ISA and resource usage look sane) -> kept off there; tests/test_gpu_f16x3.py::test_large_grid_* guards this.
+  // Interleaving the next chunk's split into the last taps is worth ~10 % on the plain kernels. The fused-tail
+  // variants keep it off: they are a handful of small launches, and the extra live registers make the 24-channel
+  // variant spill. (The wrong pixels once blamed on this combination came from the tail's matrix being read with
+  // uniform-address VECTOR loads, see hcf_step_math.h const_table(); tests/test_gpu_f16x3.py::test_large_grid_*.)
   constexpr bool INTERLEAVE = (TAILC == 0) && !HCF_DBG_NOINTER;
   static_assert(!FUSE2 || NTB == 2, "the fused 1x1 layer needs all 64 channels of the tile in one block");
   constexpr int TAPS = 9, PAD = 1;
@@ -222,10 +230,16 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       v.w = 0.f;                                                                                  \
     }                                                                                             \
     union { f16x4 h[2]; f32x4 f; } u_;                                                            \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-      const _Float16 h = (_Float16)v[e];                                                          \
-      u_.h[0][e] = h;                                                                             \
-      u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                   \
+    if (HCF_ABL & 8) { /* timing only: pretend the tensor is stored pre-split (bit mask instead of the split) */ \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
+        v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[e]) & 0x33ff33ffu);        \
+      u_.f = v;                                                                                   \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+        const _Float16 h = (_Float16)v[e];                                                        \
+        u_.h[0][e] = h;                                                                           \
+        u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                 \
+      }                                                                                           \
     }                                                                                             \
     stg[S] = u_.f;                                                                                \
   }
@@ -273,6 +287,70 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #if HCF_SETPRIO
     __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD
 #endif
+#if HCF_DXMAJOR
+    // dx-major with a sliding row window: for one dx the three dy taps touch pixel rows dy .. dy+MT-1 of the
+    // wave's MT+2 halo rows, so each row fragment is read from LDS once per dx (3 (MT+2) A reads per chunk
+    // instead of 9 MT) and every stage prefetches what the NEXT stage needs (one new row, the next tap's
+    // weights; at dy = 2 the first MT rows of the next dx) -- LDS reads, not MFMAs, burn most of the power.
+    {
+      f16x8 rh[3][MT + 2], rl[3][MT + 2], wb1[9], wb2[9];
+#define HCF_LD_ROW(DX, R)                                                                \
+      {                                                                                  \
+        const char* rec_ = lds + abase + ((R) * HW + (DX)) * REC;                        \
+        rh[DX][R] = *reinterpret_cast<const f16x8*>(rec_);                               \
+        rl[DX][R] = *reinterpret_cast<const f16x8*>(rec_ + 32);                          \
+      }
+#define HCF_LD_B(DX, DY)                                                                 \
+      {                                                                                  \
+        const char* bt_ = ldsB + bbase + ((DY) * 3 + (DX)) * (4 * BHALF);                \
+        wb1[(DX) * 3 + (DY)] = *reinterpret_cast<const f16x8*>(bt_);                     \
+        wb2[(DX) * 3 + (DY)] = *reinterpret_cast<const f16x8*>(bt_ + 2 * BHALF);         \
+      }
+      HCF_LD_B(0, 0)
+#pragma unroll
+      for (int r = 0; r < MT; ++r) HCF_LD_ROW(0, r)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int stage = dx * 3 + dy;
+          // prefetch for the next stage
+          if (dy < 2) {
+            HCF_LD_B(dx, dy + 1)
+            HCF_LD_ROW(dx, MT + dy)
+          } else if (dx < 2) {
+            HCF_LD_B(dx + 1, 0)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) HCF_LD_ROW(dx + 1, r)
+          }
+#if HCF_DX_PIN >= 2
+          __builtin_amdgcn_sched_barrier(0);      // ... and the prefetch is issued BEFORE this stage's MFMAs
+#endif
+          // the split of the NEXT chunk's staged slots rides in the MFMA shadow of the last stages
+          if (INTERLEAVE && more && !(HCF_ABL & 2) && stage >= TAPS - (NSLOT + 1) / 2) {
+            const int s0 = 2 * (stage - (TAPS - (NSLOT + 1) / 2));
+            if (s0 < NSLOT) HCF_SPLIT_SLOT(s0)
+            if (s0 + 1 < NSLOT) HCF_SPLIT_SLOT(s0 + 1)
+          }
+          const f16x8 b1 = wb1[stage], b2 = wb2[stage];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)   // a_hi * (b_hi 2^11)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[dx][m + dy], b1, acc[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)   // a_hi * (b_lo 2^11)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[dx][m + dy], b2, acc[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[dx][m + dy], b1, acc[m], 0, 0, 0);
+#if HCF_DX_PIN
+          __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance: nothing moves across stages
+#endif
+        }
+      }
+#undef HCF_LD_ROW
+#undef HCF_LD_B
+    }
+#else
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int dy = t / 3, dx = t % 3;
@@ -305,6 +383,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
     }
+#endif
 #if HCF_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -394,6 +473,8 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   if constexpr (TAILC > 0) {
     float* hl = reinterpret_cast<float*>(lds);
     const float bias_t = a.bias[oc], scale_t = a.scale[oc];
+    const int dbgsw = a.stagger;                     // HCF_DBG_TAIL bits (debugging the co-residency failure)
+    if (dbgsw & 1) { __builtin_amdgcn_s_sleep(20); __builtin_amdgcn_s_waitcnt(0); }
     __syncthreads();                                 // every wave is done with the staging buffers
     if (ocok) {
 #pragma unroll
@@ -411,7 +492,13 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       const size_t pix = (size_t)((size_t)b * H + y) * W + x;
       float z[TAILC], yv[TAILC];
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
-      step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
+      if (dbgsw & 8) {
+#pragma unroll
+        for (int c = 0; c < TAILC; ++c) yv[c] = z[c] + hl[tid * HCS + (c & 7)];
+      } else {
+        step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, (dbgsw & 4) ? a.tC : a.tns, a.tmode, (dbgsw & 2) ? nullptr : a.tmat,
+                                       a.tbias, a.tmul, yv);
+      }
       store_pixel<TAILC>(a.tzo, pix, a.tC, yv);
     }
     return;
@@ -451,7 +538,7 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
-  b.stagger = g_f16x3_ablation;
+  b.stagger = getenv("HCF_DBG_TAIL") ? atoi(getenv("HCF_DBG_TAIL")) : 0;
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
     if (a.src[i].up) b.any_up = 1;

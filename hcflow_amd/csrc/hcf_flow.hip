@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void step_head_fwd_kernel(const StepArgs a) {
   for (int c = 0; c < CMAX; ++c) z[c] = (z[c] + a.an_bias[c]) * a.an_mul[c];   // (x + b) * exp(logs)
   if (a.mat) {
     float y[CMAX];
-    matvec<CMAX>(a.mat, z, y);
+    matvec<CMAX>(const_table(a.mat), z, y);
     store_pixel<CMAX>(a.out, pix, a.C, y);
   } else {
     store_pixel<CMAX>(a.out, pix, a.C, z);

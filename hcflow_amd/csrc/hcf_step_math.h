@@ -53,9 +53,21 @@ __device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, co
   }
 }
 
+// Wave-uniform read-only tables (the C x C matrix, ActNorm vectors) are read through the constant address space:
+// scalar loads into SGPRs, which then feed the FMAs directly. Left to itself the compiler reads them with 16+
+// uniform-address vector loads per pixel once the kernel also stores to global memory (it can no longer prove
+// the table invariant).
+typedef const float __attribute__((address_space(4)))* step_cptr;
+__device__ __forceinline__ step_cptr const_table(const float* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (step_cptr)(((uint64_t)hi << 32) | lo);
+}
+
 // y = M z with M row-major [CMAX][CMAX] (host pads rows/cols beyond C with zeros)
 template <int CMAX>
-__device__ __forceinline__ void matvec(const float* __restrict__ M, const float (&z)[CMAX], float (&y)[CMAX]) {
+__device__ __forceinline__ void matvec(step_cptr M, const float (&z)[CMAX], float (&y)[CMAX]) {
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
     float acc = 0.f;
@@ -89,14 +101,15 @@ __device__ __forceinline__ void step_tail_inverse_pixel(float (&z)[CMAX], HPtr h
     for (int c = 0; c < 3; ++c) z[c] = z[c] - hp[c];
   }
   if (mat) {
-    matvec<CMAX>(mat, z, y);
+    matvec<CMAX>(const_table(mat), z, y);
   } else {
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) y[c] = z[c];
   }
   // actnorm reverse: x * exp(-logs) - bias  (ActNorms.py:54,66)
+  const step_cptr mul = const_table(an_mul), bias = const_table(an_bias);
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) y[c] = y[c] * an_mul[c] - an_bias[c];
+  for (int c = 0; c < CMAX; ++c) y[c] = y[c] * mul[c] - bias[c];
 }
 
 }  // namespace hcf

@@ -125,17 +125,20 @@ def test_f16x3_vs_exact_full_size_and_fallback():
             net.set_precision("exact")
 
 
-@pytest.mark.parametrize("B", [4])
-def test_large_grid_f16x3_matches_exact_and_is_deterministic(B):
-    """Grids with several blocks per CU (B=4 at 160x160: 1 600 / 6 400 blocks): the f16x3 path, with its fused
-    epilogues, must agree with the exact kernels and be bit-identical from run to run (a race between co-resident
-    blocks once slipped through every small-size test)."""
-    cfg = preset("SR_4X_tiny")
-    p = cached_params("SR_4X_tiny", 11)
+LARGE = [("SR_4X_tiny", 11, 4, 160), ("SR_8X_tiny", 12, 4, 80), ("Rescaling_4X_tiny", 13, 4, 160)]
+
+
+@pytest.mark.parametrize("name,seed,B,size", LARGE)
+def test_large_grid_f16x3_matches_exact_and_is_deterministic(name, seed, B, size):
+    """Grids with several blocks per CU: the f16x3 path, with its fused epilogues, must agree with the exact
+    kernels and be bit-identical from run to run (a timing-dependent fault in the fused flow-step tail once slipped
+    through every small-size test: it only showed with >= 2 co-resident blocks)."""
+    cfg = preset(name)
+    p = cached_params(name, seed)
     net = build_net(cfg, p)
     g = torch.Generator().manual_seed(21)
-    lr = torch.rand(B, 3, 160, 160, generator=g).cuda()
-    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, 160, 160)]
+    lr = torch.rand(B, 3, size, size, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, size, size)]
     with torch.no_grad():
         ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
         net.set_precision("f16x3")
@@ -148,3 +151,29 @@ def test_large_grid_f16x3_matches_exact_and_is_deterministic(B):
     with torch.no_grad():
         ex2 = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
     assert torch.equal(ex, ex2)
+
+
+def test_large_grid_forward_nll_f16x3_is_deterministic():
+    """Same for the forward (encode + NLL) pass at B = 4, HR 320x320."""
+    cfg = preset("SR_4X_tiny")
+    p = cached_params("SR_4X_tiny", 11)
+    net = build_net(cfg, p)
+    g = torch.Generator().manual_seed(22)
+    hr = torch.rand(4, 3, 320, 320, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bilinear", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    with torch.no_grad():
+        z_e, nll_e = net(hr=hr, lr=lr, reverse=False, noise=noise)
+        net.set_precision("f16x3")
+        try:
+            outs = [net(hr=hr, lr=lr, reverse=False, noise=noise) for _ in range(3)]
+        finally:
+            net.set_precision("exact")
+    assert abs(float(outs[0][1]) - float(nll_e)) <= 1e-4
+    for z, nll in outs[1:]:
+        assert torch.equal(nll, outs[0][1])
+        assert all(torch.equal(a, b) for a, b in zip(_as_list(z), _as_list(outs[0][0])))
+
+
+def _as_list(z):
+    return list(z) if isinstance(z, (list, tuple)) else [z]

@@ -2,11 +2,18 @@
 """Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) kernel trace the way `--stats` would:
     python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_kernel_stats.txt
 """
+import glob
+import os
 import sqlite3
 import sys
 
 
 def main(path):
+    if os.path.isdir(path):                      # a rocprofv3 -d directory: take the (first) results db below it
+        dbs = sorted(glob.glob(os.path.join(path, "**", "*_results.db"), recursive=True))
+        if not dbs:
+            sys.exit("no *_results.db under %s" % path)
+        path = dbs[0]
     cur = sqlite3.connect(path).cursor()
     rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
                             "max(vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name order by 3 desc"))
