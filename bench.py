@@ -32,6 +32,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec
 GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
+# (label, taps, n-tiles, kind) of the conv instantiations a pass launches; kind: see include/hcflow.h hcf_conv_time_ms
+VARIANTS = {
+    "f16x3": [("conv_f16x3_kernel<2,..> plain, <=64 out-ch", 9, 2, 0),
+              ("conv_f16x3_kernel<1,..> plain, <=32 out-ch", 9, 1, 0),
+              ("conv_f16x3_kernel<2,..,FUSE2> FCN conv1 3x3 + conv2 1x1", 9, 2, 1),
+              ("conv_f16x3_kernel<1,..,TAILC> FCN conv3 + flow-step tail", 9, 1, 2),
+              ("conv_f16x3_kernel<2,..,UP> conv_first on upsampled LR", 9, 2, 3),
+              ("conv_mfma_kernel<1,*> 1x1 convs left on the exact fp32 kernel", 1, 0, -1)],
+    "exact": [("conv_mfma_kernel<9,2>", 9, 2, -1), ("conv_mfma_kernel<9,1>", 9, 1, -1),
+              ("conv_mfma_kernel<1,2> 1x1", 1, 2, -1), ("conv_mfma_kernel<1,1> 1x1", 1, 1, -1)],
+}
 IDEAL_GB_PER_IMAGE = 23.02            # layer-wise-ideal fp32 HBM traffic per image
 
 
@@ -136,7 +147,16 @@ def main():
     if rank == 0:
         img_s = world * B * args.steps / dt
         # dominant kernel: 3x3 conv with 2 N-tiles (64 output channels): RRDB conv5 / FCN conv1
-        ms, n, fl, by = eng.conv_time(9, 2, reset=False)
+        # (f16x3: the plain instantiation only, = one rocprofv3 kernel name; the fused variants are listed below)
+        ms, n, fl, by = eng.conv_time(9, 2, kind=0 if args.precision != "exact" else -1)
+        variants = []
+        for label, taps_, nt_, kind_ in VARIANTS[args.precision]:
+            vms, vn, vfl, vby = eng.conv_time(taps_, nt_, kind=kind_)
+            if vn:
+                variants.append({"kernel": label, "launches_per_step": vn // args.steps,
+                                 "ms_per_step": round(vms / args.steps, 3),
+                                 "tflops": round((vfl / 1e12) / (vms / 1e3), 2),
+                                 "algorithmic_GBps": round((vby / 1e9) / (vms / 1e3), 1)})
         ms_all, n_all, fl_all, by_all = eng.conv_time(0, 0, reset=True)
         traffic, traffic_note = None, None
         try:    # HBM bytes per launch from a separate rocprofv3 --pmc pass over this same command (profiles/)
@@ -149,10 +169,11 @@ def main():
             pass
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         if args.precision == "exact":
-            kname, peak = "conv_mfma_kernel<9,2> (3x3, 64 out-ch, fp32 MFMA 32x32x2)", PEAK_F32_MFMA_TFLOPS
+            kname, peak = "hcf::conv_mfma_kernel<9, 2, true> (3x3, 33..64 out-ch, fp32 MFMA 32x32x2)", PEAK_F32_MFMA_TFLOPS
             pnote = "fp32 matrix peak (MI355X_MICROARCH.md)"
         else:
-            kname, peak = "conv_f16x3_kernel<9,2> (3x3, 64 out-ch, 3x f16 MFMA 32x32x16 per fp32 product block)", PEAK_F16_MFMA_TFLOPS / 3
+            kname, peak = ("hcf::f16x3::conv_f16x3_kernel<2, true, false, false, 0, 8> (3x3, 33..64 out-ch, 3x f16 MFMA "
+                           "32x32x16 per fp32 product block)"), PEAK_F16_MFMA_TFLOPS / 3
             pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts "
                      "ALGORITHMIC flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that")
         roofline = {
@@ -162,6 +183,7 @@ def main():
             "algorithmic_GB_per_launch": round(by / max(n, 1) / 1e9, 4),
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
             "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+            "conv_kernels": variants,
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / args.steps, 3),
                           "tflops": round((fl_all / 1e12) / (ms_all / 1e3), 3) if ms_all > 0 else 0.0,
                           "frac_of_step_time": round(ms_all / 1e3 / dt, 4)},

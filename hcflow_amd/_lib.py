@@ -84,7 +84,7 @@ def load() -> C.CDLL:
     lib.hcf_bench_conv.argtypes = [i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp]
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
-    lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
+    lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
                                   i32, i32, i32, fp, f32, fp, f32, fp, vp]
@@ -192,10 +192,11 @@ class Engine:
     def profile_convs(self, enable: bool):
         check(self.lib.hcf_profile_convs(self._h, int(enable)), self._h, "hcf_profile_convs")
 
-    def conv_time(self, taps: int = 0, nt: int = 0, reset: bool = False):
-        """(total_ms, launches, algorithmic_flops, algorithmic_bytes) of the recorded conv launches of one variant."""
+    def conv_time(self, taps: int = 0, nt: int = 0, reset: bool = False, kind: int = -1):
+        """(total_ms, launches, algorithmic_flops, algorithmic_bytes) of the recorded conv launches of one variant
+        (kind: 0 plain, 1 fused 1x1 second layer, 2 fused flow-step tail, 3 upsampled source, -1 any)."""
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        check(self.lib.hcf_conv_time_ms(self._h, taps, nt, int(reset), C.byref(ms), C.byref(n), C.byref(fl),
+        check(self.lib.hcf_conv_time_ms(self._h, taps, nt, kind, int(reset), C.byref(ms), C.byref(n), C.byref(fl),
                                         C.byref(by)), self._h, "hcf_conv_time_ms")
         return ms.value, n.value, fl.value, by.value
 

@@ -58,7 +58,6 @@ struct ConvArgs {
   // f16x3 kernel, optional fused inverse flow-step tail (tC > 0): z <- actnorm^-1(W^-1 coupling^-1(z, h = this conv))
   View tz; View tzo; const float* tmat; const float* tbias; const float* tmul; int tC, tns, tmode;
   const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
-  int stagger;             // unused
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };
 

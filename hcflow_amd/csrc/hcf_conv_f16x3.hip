@@ -49,7 +49,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef const float __attribute__((address_space(1)))* gfptr;
 typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 
-int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N: start stagger (x 2048 clocks) between co-resident blocks
+int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle the tall-tile variants, see launch_t)
 
 #ifndef HCF_DBG_NOZPAGE
 #define HCF_DBG_NOZPAGE 0
@@ -473,8 +473,6 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   if constexpr (TAILC > 0) {
     float* hl = reinterpret_cast<float*>(lds);
     const float bias_t = a.bias[oc], scale_t = a.scale[oc];
-    const int dbgsw = a.stagger;                     // HCF_DBG_TAIL bits (debugging the co-residency failure)
-    if (dbgsw & 1) { __builtin_amdgcn_s_sleep(20); __builtin_amdgcn_s_waitcnt(0); }
     __syncthreads();                                 // every wave is done with the staging buffers
     if (ocok) {
 #pragma unroll
@@ -492,13 +490,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       const size_t pix = (size_t)((size_t)b * H + y) * W + x;
       float z[TAILC], yv[TAILC];
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
-      if (dbgsw & 8) {
-#pragma unroll
-        for (int c = 0; c < TAILC; ++c) yv[c] = z[c] + hl[tid * HCS + (c & 7)];
-      } else {
-        step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, (dbgsw & 4) ? a.tC : a.tns, a.tmode, (dbgsw & 2) ? nullptr : a.tmat,
-                                       a.tbias, a.tmul, yv);
-      }
+      step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
       store_pixel<TAILC>(a.tzo, pix, a.tC, yv);
     }
     return;
@@ -538,7 +530,6 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
-  b.stagger = getenv("HCF_DBG_TAIL") ? atoi(getenv("HCF_DBG_TAIL")) : 0;
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
     if (a.src[i].up) b.any_up = 1;

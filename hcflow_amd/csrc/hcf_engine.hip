@@ -165,7 +165,7 @@ struct hcf_engine {
   std::string err;
   // conv profiling
   bool prof = false;
-  struct ProfRec { hipEvent_t e0, e1; int taps, nt; double flops, bytes; };
+  struct ProfRec { hipEvent_t e0, e1; int taps, nt, kind; double flops, bytes; };
   std::vector<ProfRec> prof_events;
   size_t prof_used = 0;
   // build state
@@ -545,6 +545,11 @@ struct hcf_engine {
       }
       prof_events[prof_used].taps = cv.taps;
       prof_events[prof_used].nt = cv.npad / 32;
+      {   // kernel variant: 0 plain, 1 + fused 1x1 second layer, 2 + fused flow-step tail, 3 a source is read upsampled
+        bool up = false;
+        for (int i = 0; i < cv.nsrc; ++i) up = up || srcs[i].up > 0;
+        prof_events[prof_used].kind = tail ? 2 : fuse2 ? 1 : up ? 3 : 0;
+      }
       prof_events[prof_used].flops = (cv.flops_per_pixel + (fuse2 ? fuse2->flops_per_pixel : 0.0)) * (double)B_ * H * W;
       {   // algorithmic HBM bytes: every source window read once, output written once, residuals read once, weights once
         double px_bytes = 4.0 * cv.cout * (1 + (res1.p ? 1 : 0) + (res2.p ? 1 : 0));
@@ -1095,14 +1100,14 @@ int hcf_profile_convs(hcf_engine* e, int enable) {
   return HCF_OK;
 }
 
-int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t reset, double* total_ms, int64_t* launches,
-                     double* flops, double* bytes) {
+int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t kind, int32_t reset, double* total_ms,
+                     int64_t* launches, double* flops, double* bytes) {
   if (!e) return HCF_ERR_ARG;
   double tot = 0, fl = 0, by = 0;
   int64_t n = 0;
   for (size_t i = 0; i < e->prof_used; ++i) {
     const auto& r = e->prof_events[i];
-    if ((taps && r.taps != taps) || (nt && r.nt != nt)) continue;
+    if ((taps && r.taps != taps) || (nt && r.nt != nt) || (kind >= 0 && r.kind != kind)) continue;
     if (hipEventSynchronize(r.e1) != hipSuccess) return HCF_ERR_HIP;
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return HCF_ERR_HIP;

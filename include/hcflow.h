@@ -137,12 +137,13 @@ size_t hcf_weight_bytes(const hcf_engine* e);
 
 /* timing hook used by bench.py: when enabled, every conv launch is bracketed by HIP events on the
  * launch stream. hcf_conv_time_ms() sums the recorded launches of one kernel variant
- * (taps in {9,1} = 3x3 / 1x1, nt = N tiles of 32 output channels; 0 = any): total time, launch count
+ * (taps in {9,1} = 3x3 / 1x1, nt = N tiles of 32 output channels; 0 = any; kind = 0 plain conv, 1 with the fused
+ * 1x1 second layer, 2 with the fused flow-step tail, 3 reading an upsampled source, -1 any): total time, launch count,
  * algorithmic FLOPs (2 * taps * cin * cout per output pixel) and algorithmic HBM bytes (each source window,
  * residual and the weights read once, the output written once). reset != 0 clears the records. */
 int hcf_profile_convs(hcf_engine* e, int enable);
-int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t reset, double* total_ms, int64_t* launches,
-                     double* flops, double* bytes);
+int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t kind, int32_t reset, double* total_ms,
+                     int64_t* launches, double* flops, double* bytes);
 
 /* ---- per-op entry points (unit parity tests; tensors are device NCHW fp32) ------------------- */
 /* F.conv2d(x, w, stride 1, padding k/2) with the fused epilogue
