@@ -20,6 +20,7 @@ The JSON line also carries
                 path) timed on this host on a bounded sample (B=1 patches), rank 0, N = 1 only.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -81,7 +82,8 @@ def main():
 
     cfg = preset(args.preset)
     params = make_params(cfg, 1234)
-    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    with contextlib.redirect_stdout(sys.stderr):     # the constructor prints the reference's `shapes:` line; stdout carries only the JSON
+        net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
     net.load_state_dict(params, strict=True)
     for m in net.modules():
         if "ActNorm" in type(m).__name__:

@@ -25,6 +25,7 @@ SYMBOLS = [
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
+    "hcf_actnorm_init_request", "hcf_get_param",
 ]
 
 
@@ -86,6 +87,8 @@ def load() -> C.CDLL:
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
     lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.hcf_actnorm_init_request.argtypes = [vp, C.POINTER(C.c_char_p), i32]
+    lib.hcf_get_param.argtypes = [vp, C.c_char_p, fp, i64]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
                                   i32, i32, i32, fp, f32, fp, f32, fp, vp]
     lib.hcf_op_squeeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
@@ -177,6 +180,19 @@ class Engine:
         shape = (C.c_int64 * 4)(*([int(s) for s in t.shape] + [1] * (4 - t.dim())))
         check(self.lib.hcf_set_param(self._h, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()), self._h,
               "hcf_set_param(%s)" % key)
+
+    def actnorm_init_request(self, prefixes):
+        """Arm the next forward pass to fit the listed ActNorms from its data (include/hcflow.h)."""
+        arr = (C.c_char_p * len(prefixes))(*[p.encode() for p in prefixes])
+        check(self.lib.hcf_actnorm_init_request(self._h, arr, len(prefixes)), self._h, "hcf_actnorm_init_request")
+
+    def get_param(self, key: str, numel: int):
+        """The engine's host copy of a parameter as a flat fp32 CPU tensor."""
+        import torch
+        out = torch.empty(int(numel), dtype=torch.float32)
+        check(self.lib.hcf_get_param(self._h, key.encode(), C.c_void_p(out.data_ptr()), int(numel)), self._h,
+              "hcf_get_param(%s)" % key)
+        return out
 
     def finalize(self, device: int):
         check(self.lib.hcf_finalize(self._h, int(device)), self._h, "hcf_finalize")

@@ -225,8 +225,7 @@ class FlowNet(nn.Module):
             C = ns
             self.output_shapes.append([-1, C, H, W])
         self.H, self.W = H, W
-        # (the reference prints this list at construction, FlowNet_SR_x4.py:71; kept as an attribute only so
-        #  that stdout stays clean for tools that parse it, e.g. bench.py's single JSON line)
+        print('shapes:', self.output_shapes)      # FlowNet_SR_x4.py:71 (part of the boundary's observable behaviour)
 
 
 # ------------------------------------------------------------------ engine-backed top modules
@@ -276,17 +275,40 @@ class _EngineModule(nn.Module):
             ent["stamp"] = stamp
         return ent["engine"], idx
 
-    def _check_inference(self):
+    def _check_inference(self, reverse=False):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
                 "hcflow_amd round 1 implements the forward/inverse inference path; the backward pass "
                 "(train_HCFlow.py optimize_parameters) is SURVEY.md section 8f rank 1. Call under torch.no_grad().")
-        if self.training:
-            for m in self.modules():
-                if isinstance(m, ActNorm2d) and not m.inited:
-                    raise NotImplementedError(
-                        "ActNorm data-dependent initialisation (ActNorms.py:29-43) belongs to the training "
-                        "path (SURVEY.md 8f rank 1); load a checkpoint / set .inited = True or call .eval().")
+        if self.training and reverse and self._pending_actnorms():
+            raise NotImplementedError(
+                "un-initialised ActNorm layers in train() mode on the REVERSE path: the reference would fit them to "
+                "the reverse-direction activations (ActNorms.py:78-80), which no shipped configuration does; run one "
+                "forward (hr -> z) pass first, load a checkpoint / set .inited = True, or call .eval().")
+
+    # -- ActNorm data-dependent initialisation (ActNorms.py:29-43): fitted by the engine during ONE forward pass
+    def _pending_actnorms(self):
+        return [(k, m) for k, m in self.named_modules() if isinstance(m, ActNorm2d) and not m.inited]
+
+    def _arm_actnorm_init(self, eng):
+        """train() mode and ``inited == False`` -> the next forward pass fits bias / logs (eval() mode never
+        initialises, ActNorms.py:31-32)."""
+        pend = self._pending_actnorms() if self.training else []
+        if pend:
+            eng.actnorm_init_request([k for k, _ in pend])
+        return pend
+
+    def _finish_actnorm_init(self, eng, idx, pend):
+        if not pend:
+            return
+        with torch.no_grad():
+            for k, m in pend:
+                n = m.bias.numel()
+                m.bias.copy_(eng.get_param(k + ".bias", n).view_as(m.bias))
+                m.logs.copy_(eng.get_param(k + ".logs", n).view_as(m.logs))
+                m.inited = True
+        # the engine already holds these values: no repack on the next call
+        self._engines[idx]["stamp"] = tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     @staticmethod
     def _prep(t: torch.Tensor, device) -> torch.Tensor:
@@ -297,7 +319,7 @@ class _EngineModule(nn.Module):
         return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
     def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None):
-        self._check_inference()
+        self._check_inference(reverse=True)
         dev = next(self.parameters()).device
         eng, idx = self._engine_for(dev)
         lr = self._prep(lr, dev)
@@ -367,11 +389,13 @@ class HCFlowNet_SR(_EngineModule):
         nll = torch.empty(1, device=dev)
         logdet = torch.empty(B, device=dev)
         zraw = torch.empty(B, 3, H // s, W // s, device=dev) if return_internals else None
+        pend = self._arm_actnorm_init(eng)
         with torch.cuda.device(idx):
             rc = eng.lib.hcf_forward_sr(eng.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(),
                                         noise.data_ptr(), out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(),
                                         None if zraw is None else zraw.data_ptr(), B, H, W, self._stream(idx))
         _lib.check(rc, eng.handle, "hcf_forward_sr")
+        self._finish_actnorm_init(eng, idx, pend)
         if return_internals:
             return out_lr, nll[0], logdet, zraw
         return out_lr, nll[0]
@@ -410,10 +434,12 @@ class HCFlowNet_Rescaling(_EngineModule):
         c1 = cfg.level_channels(1) - cfg.split_channels(1)
         z1 = torch.empty(B, c0, H // 2, W // 2, device=dev)
         z2 = torch.empty(B, c1, H // 4, W // 4, device=dev)
+        pend = self._arm_actnorm_init(eng)
         with torch.cuda.device(idx):
             rc = eng.lib.hcf_forward_rescale(eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(),
                                              B, H, W, 0 if clamp else _lib.FLAG_NO_CLAMP, self._stream(idx))
         _lib.check(rc, eng.handle, "hcf_forward_rescale")
+        self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 
     def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):

@@ -128,5 +128,7 @@ int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, i
 int launch_reduce_partials(const float* partial, int stride, int n, int B, double cst, double pixels,
                            float* out_logdet, float* out_nll, hipStream_t st);
 int launch_fill(float* p, size_t n, float v, hipStream_t st);
+// out[0..n) = per-channel sum, out[n..2n) = per-channel sum of squares over all B*H*W pixels of the window (double)
+int launch_channel_stats(View v, int B, int H, int W, double* out, hipStream_t st);
 
 }  // namespace hcf

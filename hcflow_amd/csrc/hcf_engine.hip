@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <vector>
@@ -42,6 +43,7 @@ struct Conv {
   float *wpack = nullptr, *bias = nullptr, *scale = nullptr;   // device
   float* wpack16 = nullptr;                                     // device, f16x3 split pack (or null: exact only)
   double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
+  std::string an_key;                                           // Basic.Conv2d: prefix of its ActNorm ("....conv1.actnorm")
 };
 
 struct Step {
@@ -51,6 +53,8 @@ struct Step {
   Conv c[5];                        // FCN: c[0..2]; DenseBlock: c[0..4]
   float *mat_inv = nullptr, *mat_fwd = nullptr, *bias = nullptr, *mul_inv = nullptr, *mul_fwd = nullptr;
   double ld_const = 0;              // per pixel: sum(actnorm logs) + slogdet(W)
+  double lad = 0;                   // slogdet(W) alone
+  std::string an_key;               // prefix of the step's ActNorm ("....actnorm")
 };
 
 struct Rdb { Conv c[5]; };
@@ -176,6 +180,11 @@ struct hcf_engine {
   bool use_f16 = false;        // precision of the pass being enqueued
   int* ovf_flag = nullptr;     // device: [0] = range flag, bytes 64..191 = zero page for the f16x3 kernel
   int64_t n_fallbacks = 0;
+  // ActNorm data-dependent initialisation (ActNorms.py:29-43), armed for ONE forward pass by hcf_actnorm_init_request
+  std::set<std::string> an_pending;
+  bool an_active = false;
+  double* stats_dev = nullptr;   // 2 * 256 doubles
+  float* unit_dev = nullptr;     // [0,256) zeros, [256,512) ones: identity epilogue of the statistics pass
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -285,6 +294,7 @@ struct hcf_engine {
     if (al)
       for (int i = 0; i < cout; ++i) sc[i] = expf(al[i]);
     pack_conv(cv, w, ab, al ? sc.data() : nullptr, cin, cout, k, srcs, ACT_RELU);
+    cv.an_key = p + ".actnorm";
   }
   // Basic.Conv2dZeros (Basic.py:57-72): (conv + bias) * exp(logs * 3)
   void build_conv_zeros(Conv& cv, const std::string& p, int cin, int cout, std::vector<int> srcs) {
@@ -346,6 +356,7 @@ struct hcf_engine {
     s.lr_vs_others = lr_vs_others;
     s.hid = hid;
     s.fcn = (nn_module == HCF_NN_FCN);
+    s.an_key = p + ".actnorm";
     if (s.cmax < 0) { fail(HCF_ERR_UNSUPPORTED, "flow step with more than 48 channels"); return; }
     const float* ab = P(p + ".actnorm.bias", {1, C, 1, 1});
     const float* al = P(p + ".actnorm.logs", {1, C, 1, 1});
@@ -407,6 +418,7 @@ struct hcf_engine {
         }
       s.mat_inv = upload(wi);
       s.mat_fwd = upload(wf);
+      s.lad = lad;
       s.ld_const += lad;
     }
   }
@@ -489,6 +501,7 @@ struct hcf_engine {
   void free_weights() {
     for (float* p : dev_allocs) hipFree(p);
     dev_allocs.clear();
+    unit_dev = nullptr;
     weight_bytes = 0;
   }
 
@@ -589,6 +602,92 @@ struct hcf_engine {
     }                                                       \
   } while (0)
 
+  // ---- ActNorm data-dependent init ----------------------------------------------------------------------------
+  bool an_wants(const std::string& key) const { return an_active && !arena.dry && an_pending.count(key) > 0; }
+
+  // `initialize_parameters` on the tensor that reaches the layer: false when the stored bias is non-zero ("already
+  // trained", ActNorms.py:33-35); otherwise bias = -mean, logs = log(scale / (sqrt(var) + 1e-6)) over (B, H, W)
+  // (:37-43; scale = 1 for every ActNorm of these nets) are written to the host parameter table.
+  bool an_fit(const std::string& key, View v, int H, int W) {
+    an_pending.erase(key);
+    auto ib = params.find(key + ".bias"), il = params.find(key + ".logs");
+    if (ib == params.end() || il == params.end() || (int)ib->second.data.size() != v.n) {
+      fail(HCF_ERR_KEY, "ActNorm init: unknown layer " + key);
+      return false;
+    }
+    for (float x : ib->second.data)
+      if (x != 0.f) return false;
+    if (!stats_dev && hipMalloc((void**)&stats_dev, sizeof(double) * 512) != hipSuccess) {
+      fail(HCF_ERR_NOMEM, "hipMalloc failed for the ActNorm statistics");
+      return false;
+    }
+    std::vector<double> hs(2 * (size_t)v.n);
+    if (launch_channel_stats(v, B_, H, W, stats_dev, st) != HCF_OK ||
+        hipMemcpyAsync(hs.data(), stats_dev, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      fail(HCF_ERR_HIP, "ActNorm statistics failed for " + key);
+      return false;
+    }
+    const double n = (double)B_ * H * W;
+    for (int c = 0; c < v.n; ++c) {
+      const double mean = hs[c] / n;
+      const double var = std::max(0.0, hs[v.n + c] / n - mean * mean);
+      ib->second.data[c] = (float)(-mean);
+      il->second.data[c] = (float)log(1.0 / (sqrt(var) + 1e-6));
+    }
+    return true;
+  }
+
+  bool an_upload(float* dst, const std::vector<float>& v) {
+    if (hipMemcpy(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      fail(HCF_ERR_HIP, "hipMemcpy H2D failed (ActNorm init)");
+      return false;
+    }
+    return true;
+  }
+
+  void an_refit_step(Step& s, View z, int H, int W) {
+    if (!an_fit(s.an_key, z, H, W)) return;
+    const std::vector<float>& b = params[s.an_key + ".bias"].data;
+    const std::vector<float>& l = params[s.an_key + ".logs"].data;
+    std::vector<float> bias(s.cmax, 0.f), mi(s.cmax, 0.f), mf(s.cmax, 0.f);
+    double sumlogs = 0;
+    for (int c = 0; c < s.C; ++c) {
+      bias[c] = b[c]; mi[c] = expf(-l[c]); mf[c] = expf(l[c]);
+      sumlogs += (double)l[c];
+    }
+    if (an_upload(s.bias, bias) && an_upload(s.mul_inv, mi) && an_upload(s.mul_fwd, mf)) s.ld_const = sumlogs + s.lad;
+  }
+
+  void an_refit_conv(Conv& cv, View y, int H, int W) {
+    if (!an_fit(cv.an_key, y, H, W)) return;
+    const std::vector<float>& b = params[cv.an_key + ".bias"].data;
+    const std::vector<float>& l = params[cv.an_key + ".logs"].data;
+    std::vector<float> bias(cv.npad, 0.f), sc(cv.npad, 1.f);
+    for (int c = 0; c < cv.cout; ++c) { bias[c] = b[c]; sc[c] = expf(l[c]); }
+    an_upload(cv.bias, bias) && an_upload(cv.scale, sc);
+  }
+
+  // Basic.Conv2d (conv -> ActNorm -> ReLU). While an init pass is armed and this layer is pending, the raw conv
+  // output is produced first (identity epilogue), its statistics fix bias / logs, then the layer runs normally.
+  void run_conv_an(const Conv& cv, std::vector<View> in, int H, int W, View out) {
+    if (an_wants(cv.an_key)) {
+      if (!unit_dev) {
+        std::vector<float> u(512, 0.f);
+        for (int i = 256; i < 512; ++i) u[i] = 1.f;
+        unit_dev = upload(u);
+      }
+      if (unit_dev) {
+        Conv raw = cv;
+        raw.bias = unit_dev; raw.scale = unit_dev + 256; raw.act = ACT_NONE;
+        run_conv(raw, in, H, W, out);
+        View y = out; y.n = cv.cout;
+        an_refit_conv(const_cast<Conv&>(cv), y, H, W);
+      }
+    }
+    run_conv(cv, in, H, W, out);
+  }
+
   struct Scratch {      // per-level temporaries
     Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow;
   };
@@ -614,8 +713,8 @@ struct hcf_engine {
         const View none = mkview(nullptr, 0, 0, 0);
         run_conv(s.c[0], in, H, W, sc.h2.v(0, s.hid), none, 0.f, none, 0.f, &s.c[1]);
       } else {
-        run_conv(s.c[0], in, H, W, sc.h1.v(0, s.hid));
-        run_conv(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
+        run_conv_an(s.c[0], in, H, W, sc.h1.v(0, s.hid));
+        run_conv_an(s.c[1], {sc.h1.v(0, s.hid)}, H, W, sc.h2.v(0, s.hid));
       }
       {
         const View none = mkview(nullptr, 0, 0, 0);
@@ -666,6 +765,7 @@ struct hcf_engine {
     a.B = B_; a.H = H; a.W = W; a.C = s.C; a.ns = s.ns; a.mode = s.mode;
     a.z = z.all(); a.out = z.all();
     a.mat = s.has_mat ? s.mat_fwd : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_fwd;
+    if (an_wants(s.an_key)) an_refit_step(const_cast<Step&>(s), z.all(), H, W);     // same device arrays, new contents
     HCF_LAUNCH(launch_step_head_fwd(a, st));
     run_coupling_net(s, step_z1(s, z), u, H, W, sc);
     a.h = sc.hout.v(0, s.f_out);
@@ -834,12 +934,11 @@ struct hcf_engine {
     const bool want_ld = sr();
     // partial-sum slots
     int nslots = 0;
-    double ld_const = sr() ? -log((double)cfg.quant) * (double)H0 * W0 : 0.0;
     for (int level = 0; level < L; ++level) {
       const int H = H0 >> (level + 1), W = W0 >> (level + 1);
       const int nb = step_blocks_per_sample(H, W);
-      for (const Step& s : levels[level].steps) { if (s.mode == CPL_AFFINE) nslots += nb; ld_const += s.ld_const * H * W; }
-      for (const Step& s : levels[level].cf.steps) { if (s.mode == CPL_AFFINE) nslots += nb; ld_const += s.ld_const * H * W; }
+      for (const Step& s : levels[level].steps) if (s.mode == CPL_AFFINE) nslots += nb;
+      for (const Step& s : levels[level].cf.steps) if (s.mode == CPL_AFFINE) nslots += nb;
       nslots += nb;                      // gaussian logp
     }
     nslots += step_blocks_per_sample(H0 >> L, W0 >> L);   // Dirac term
@@ -912,6 +1011,14 @@ struct hcf_engine {
       pslot += step_blocks_per_sample(h, w);
       HCF_LAUNCH(launch_quant_logp(zlr, lr, out_lr, B, h, w, lr ? pp : nullptr, nslots, st));
       if (pslot > nslots) fail(HCF_ERR_STATE, "internal: partial slot overflow");
+      // data-independent log-det terms: -ln(quant) HW + sum over steps of (sum(actnorm logs) + slogdet W) * pixels
+      // (summed here, after the steps ran: an ActNorm init pass changes them on the way)
+      double ld_const = -log((double)cfg.quant) * (double)H0 * W0;
+      for (int level = 0; level < L; ++level) {
+        const double px = (double)(H0 >> (level + 1)) * (W0 >> (level + 1));
+        for (const Step& s : levels[level].steps) ld_const += s.ld_const * px;
+        for (const Step& s : levels[level].cf.steps) ld_const += s.ld_const * px;
+      }
       HCF_LAUNCH(launch_reduce_partials(partial, nslots, nslots, B, ld_const, (double)H0 * W0, out_logdet, out_nll, st));
     } else {
       HCF_LAUNCH(launch_nhwc_to_nchw(zlr, out_lr, B, 3, h, w, (flags & HCF_FLAG_NO_CLAMP) ? 0 : 1, st));
@@ -925,14 +1032,14 @@ struct hcf_engine {
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
     st = stream;
-    use_f16 = (precision == PREC_F16X3);      // also during the sizing run: fusion decisions must not differ
+    use_f16 = (precision == PREC_F16X3) && !an_active;   // also during the sizing run: fusion decisions must not differ
     arena.dry = true;
     arena.peak = 0;
     body();
     arena.dry = false;
     if (rc != HCF_OK) return rc;
     if (ensure_arena(arena.peak) != HCF_OK) return rc;
-    use_f16 = (precision == PREC_F16X3);
+    use_f16 = (precision == PREC_F16X3) && !an_active;   // statistics passes run on the exact kernels
     if (use_f16) {
       if (!ovf_flag && hipMalloc((void**)&ovf_flag, 256) != hipSuccess)
         return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
@@ -952,6 +1059,8 @@ struct hcf_engine {
       }
     }
     use_f16 = false;
+    an_active = false;
+    an_pending.clear();
     return rc;
   }
   uint32_t pass_flags = 0;
@@ -996,6 +1105,7 @@ void hcf_destroy(hcf_engine* e) {
   e->free_weights();
   if (e->arena.base) hipFree(e->arena.base);
   if (e->ovf_flag) hipFree(e->ovf_flag);
+  if (e->stats_dev) hipFree(e->stats_dev);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
@@ -1092,6 +1202,29 @@ int64_t hcf_fallback_count(const hcf_engine* e) { return e ? e->n_fallbacks : -1
 
 size_t hcf_workspace_bytes(const hcf_engine* e) { return e ? e->arena.cap : 0; }
 size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }
+
+int hcf_actnorm_init_request(hcf_engine* e, const char* const* prefixes, int32_t n) {
+  if (!e || n < 0 || (n > 0 && !prefixes)) return HCF_ERR_ARG;
+  if (!e->finalized) return e->fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
+  e->an_pending.clear();
+  for (int i = 0; i < n; ++i) {
+    if (!prefixes[i]) return HCF_ERR_ARG;
+    const std::string k(prefixes[i]);
+    if (!e->params.count(k + ".bias") || !e->params.count(k + ".logs")) return e->fail(HCF_ERR_KEY, "not an ActNorm: " + k);
+    e->an_pending.insert(k);
+  }
+  e->an_active = n > 0;
+  return HCF_OK;
+}
+
+int hcf_get_param(hcf_engine* e, const char* key, float* out, int64_t numel) {
+  if (!e || !key || !out) return HCF_ERR_ARG;
+  auto it = e->params.find(key);
+  if (it == e->params.end() || !it->second.set) return e->fail(HCF_ERR_KEY, std::string("unknown or unset parameter: ") + key);
+  if ((int64_t)it->second.data.size() != numel) return e->fail(HCF_ERR_SHAPE, std::string("size mismatch for parameter: ") + key);
+  memcpy(out, it->second.data.data(), sizeof(float) * (size_t)numel);
+  return HCF_OK;
+}
 
 int hcf_profile_convs(hcf_engine* e, int enable) {
   if (!e) return HCF_ERR_ARG;

@@ -416,6 +416,36 @@ __global__ __launch_bounds__(256) void fill_kernel(float* p, size_t n, float v) 
 
 #define HCF_RET() return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP
 
+// ---- per-channel statistics (ActNorm data-dependent init, ActNorms.py:37-43) ------------------------------------
+// out[c] += sum over (b, y, x) of v[c];  out[n + c] += sum of v[c]^2, in double (atomics): the host turns them into
+// bias = -mean, logs = log(scale / (sqrt(var) + 1e-6)). Consecutive threads read consecutive floats of the NHWC
+// window (thread -> (pixel group, channel)); one block covers `ppb` pixels.
+__global__ __launch_bounds__(256) void channel_stats_kernel(View v, long long npix, int ppb, double* out) {
+  __shared__ double sh[2][256];
+  const int n = v.n;
+  const int groups = 256 / n;                  // pixels handled concurrently by one block (n <= 256)
+  const int pg = threadIdx.x / n, c = threadIdx.x - pg * n;
+  double s = 0.0, q = 0.0;
+  if (pg < groups) {
+    const long long p0 = (long long)blockIdx.x * ppb;
+    const long long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    for (long long p = p0 + pg; p < p1; p += groups) {
+      const float x = v.p[(size_t)p * v.cs + v.c0 + c];
+      s += (double)x;
+      q += (double)x * (double)x;
+    }
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < n) {
+    double ts = 0.0, tq = 0.0;
+    for (int g = 0; g < groups; ++g) { ts += sh[0][g * n + threadIdx.x]; tq += sh[1][g * n + threadIdx.x]; }
+    atomicAdd(out + threadIdx.x, ts);
+    atomicAdd(out + n + threadIdx.x, tq);
+  }
+}
+
 int launch_nchw_to_nhwc(const float* src, View dst, int B, int C, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, pix_grid(B, H, W), dim3(256), 0, st, src, dst, C, H * W);
   HCF_RET();
@@ -475,6 +505,15 @@ int launch_reduce_partials(const float* partial, int stride, int n, int B, doubl
 int launch_fill(float* p, size_t n, float v, hipStream_t st) {
   if (n == 0) return HCF_OK;
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  HCF_RET();
+}
+
+int launch_channel_stats(View v, int B, int H, int W, double* out, hipStream_t st) {
+  if (v.n < 1 || v.n > 256) return HCF_ERR_ARG;
+  if (hipMemsetAsync(out, 0, sizeof(double) * 2 * v.n, st) != hipSuccess) return HCF_ERR_HIP;
+  const long long npix = (long long)B * H * W;
+  const int ppb = 4096;
+  hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, st, v, npix, ppb, out);
   HCF_RET();
 }
 

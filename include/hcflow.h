@@ -135,6 +135,17 @@ int64_t hcf_fallback_count(const hcf_engine* e);
 size_t hcf_workspace_bytes(const hcf_engine* e);
 size_t hcf_weight_bytes(const hcf_engine* e);
 
+/* ActNorm data-dependent initialisation (reference: _ActNorm.initialize_parameters, ActNorms.py:29-43, reached from
+ * _ActNorm.forward when `not self.inited` in train() mode, :78-80). hcf_actnorm_init_request() arms the NEXT
+ * hcf_forward_sr / hcf_forward_rescale call: each listed ActNorm (state_dict prefix, e.g.
+ * "flow.layers.1.actnorm" or "flow.layers.1.affine.f.conv1.actnorm") whose stored bias is all zero gets
+ * bias = -mean, logs = log(1 / (sqrt(var) + 1e-6)) of the tensor that reaches it, per channel over (B, H, W), in
+ * forward order, and the pass continues with the fitted values (the pass runs on the exact fp32 kernels and
+ * synchronises the stream once per fitted layer). Afterwards hcf_get_param() returns the fitted tensors (HOST
+ * buffer of `numel` floats; works for any parameter key) so that the caller can store them in its own module. */
+int hcf_actnorm_init_request(hcf_engine* e, const char* const* prefixes, int32_t n);
+int hcf_get_param(hcf_engine* e, const char* key, float* host_out, int64_t numel);
+
 /* timing hook used by bench.py: when enabled, every conv launch is bracketed by HIP events on the
  * launch stream. hcf_conv_time_ms() sums the recorded launches of one kernel variant
  * (taps in {9,1} = 3x3 / 1x1, nt = N tiles of 32 output channels; 0 = any; kind = 0 plain conv, 1 with the fused

@@ -138,6 +138,31 @@ def actnorm_data_init(x: torch.Tensor, scale: float = 1.0):
     return bias, logs
 
 
+class InitParams(dict):
+    """A parameter dict that also carries the set of ActNorm prefixes still awaiting their data-dependent
+    initialisation (``module.inited == False`` in train() mode, ActNorms.py:29-43,78-80). The forward functions
+    below fit and store bias / logs for those prefixes on the first tensor that reaches them, exactly where the
+    reference's ``_ActNorm.forward`` does, and then use the fitted values."""
+
+    def __init__(self, params, prefixes):
+        super().__init__(params)
+        self.pending = set(prefixes)
+
+
+def maybe_actnorm_init(p, pre: str, x: torch.Tensor, scale: float = 1.0):
+    """``if not self.inited: self.initialize_parameters(input)`` (ActNorms.py:78-80): a non-zero bias means
+    "already trained" (:33-35), otherwise fit (:37-43)."""
+    pending = getattr(p, "pending", None)
+    if not pending or pre not in pending:
+        return
+    pending.discard(pre)
+    if bool((p[pre + ".bias"] != 0).any()):
+        return
+    bias, logs = actnorm_data_init(x, scale)
+    p[pre + ".bias"] = bias
+    p[pre + ".logs"] = logs
+
+
 def invconv_forward(x, W):
     """InvertibleConv1x1 forward (Permutations.py:70-71,99-100): z = conv2d(x, W[:, :, None, None])."""
     C = W.shape[0]
@@ -165,6 +190,7 @@ def logscale_of(scale):
 def conv_actnorm(x, p: P, pre: str, pad: int):
     """Basic.Conv2d with do_actnorm=True (Basic.py:14-53): bias-free conv then ActNorm (no logdet)."""
     y = F.conv2d(x, p[pre + ".weight"], None, 1, pad)
+    maybe_actnorm_init(p, pre + ".actnorm", y)
     return actnorm_forward(y, p[pre + ".actnorm.bias"], p[pre + ".actnorm.logs"])
 
 
@@ -252,6 +278,7 @@ def flowstep_forward(z, u, logdet, p: P, pre: str, perm: str, kind: str, nn_modu
     (or None, as the rescaling net passes) and is updated in the reference's order."""
     B, C, H, W = z.shape
     pix = H * W
+    maybe_actnorm_init(p, pre + ".actnorm", z)
     z = actnorm_forward(z, p[pre + ".actnorm.bias"], p[pre + ".actnorm.logs"])
     if logdet is not None:
         logdet = logdet + actnorm_logdet(p[pre + ".actnorm.logs"], pix)

@@ -155,6 +155,45 @@ def gen_net_fixture(name, preset_name, ref_sr, ref_rs, B, h, w, seed, taus=(0.0,
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_aninit_fixture(name, preset_name, ref_sr, ref_rs, B, h, w, seed):
+    """ActNorm data-dependent initialisation (ActNorms.py:29-43): our seeded weights with every ActNorm's bias / logs
+    zeroed and ``inited = False``, ONE forward pass in train() mode; records the parameters the reference fits and
+    the outputs of that same pass."""
+    cfg = preset(preset_name)
+    net, params = build(ref_sr if cfg.sr else ref_rs, cfg, seed)
+    an = [(k, m) for k, m in net.named_modules() if "ActNorm" in type(m).__name__]
+    for _, m in an:
+        m.bias.data.zero_()
+        m.logs.data.zero_()
+        m.inited = False
+    net.train()
+    g = torch.Generator().manual_seed(seed + 29)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=g)
+    lr = torch.rand(B, 3, h, w, generator=g)
+    out = {"preset": preset_name, "seed": seed, "hr": np_(hr), "lr": np_(lr)}
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    with torch.no_grad():
+        if cfg.sr:
+            with Capture() as cap:
+                lr_hat, nll = net(hr=hr, lr=lr, reverse=False)
+            out.update(fwd_noise=np_(cap.rand[0]), fwd_lr=np_(lr_hat), fwd_nll=np.float64(float(nll)))
+            print("  %s nll after init %.6f" % (name, float(nll)))
+        else:
+            lr_hat, z1, z2 = net(hr=hr, reverse=False)
+            out.update(fwd_lr=np_(lr_hat), fwd_z1=np_(z1), fwd_z2=np_(z2))
+    assert all(m.inited for _, m in an)
+    out["an_keys"] = np.array([k for k, _ in an])
+    for i, (k, m) in enumerate(an):
+        out["an_bias_%d" % i] = np_(m.bias).reshape(-1)
+        out["an_logs_%d" % i] = np_(m.logs).reshape(-1)
+    print("  %s: %d ActNorms fitted, logs range [%.3f, %.3f]" % (
+        name, len(an), min(float(m.logs.min()) for _, m in an), max(float(m.logs.max()) for _, m in an)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def gen_op_fixture(ref_sr, ref_rs):
     """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
     from models.modules import Basic, thops
@@ -261,6 +300,13 @@ def gen_op_fixture(ref_sr, ref_rs):
 def main():
     torch.set_num_threads(8)
     ref_sr, ref_rs = import_reference()
+    only = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if only in ("all", "aninit"):
+        gen_aninit_fixture("aninit_sr4_tiny", "SR_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=31)
+        gen_aninit_fixture("aninit_sr8_tiny", "SR_8X_tiny", ref_sr, ref_rs, B=2, h=5, w=6, seed=32)
+        gen_aninit_fixture("aninit_rescale_tiny", "Rescaling_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=33)
+        if only == "aninit":
+            return
     gen_op_fixture(ref_sr, ref_rs)
     # reduced-depth nets with the real channel widths, odd-ish spatial sizes, B=2
     gen_net_fixture("net_sr4_tiny", "SR_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=11)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import hcflow_oracle as O
 from hcflow_amd.config import preset, eps_shapes
-from tests.util import load_golden, params_for, t, maxdiff
+from tests.util import load_golden, params_for, t, maxdiff, cached_params
 
 pytestmark = pytest.mark.gpu
 
@@ -152,3 +152,77 @@ def test_parameter_update_triggers_repack():
         net.flow.level0_condFlow.f.bias.sub_(0.05)
         c = net(lr=lr, eps_std=0.0, reverse=True)
     assert not torch.equal(a, b) and maxdiff(a, c) <= 1e-6
+
+
+ANINIT = ["aninit_sr4_tiny", "aninit_sr8_tiny", "aninit_rescale_tiny"]
+
+
+@pytest.mark.parametrize("name", ANINIT)
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+def test_actnorm_data_init_pass(name, precision):
+    """train() mode, every ActNorm zeroed and ``inited = False``: ONE forward pass fits bias / logs where the
+    reference does (ActNorms.py:29-43,78-80), returns the reference's outputs, stores the fitted values in the
+    module's parameters and flips ``inited``; the following eval() pass uses them."""
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    keys = [str(k) for k in g["an_keys"]]
+    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    mods = dict(net.named_modules())
+    with torch.no_grad():
+        for k in keys:
+            mods[k].bias.zero_()
+            mods[k].logs.zero_()
+            assert mods[k].inited is False
+    net = net.to("cuda:0").train().set_precision(precision)
+    hr = t(g["hr"]).cuda()
+    with torch.no_grad():
+        if cfg.sr:
+            lr_hat, nll = net(hr=hr, lr=t(g["lr"]).cuda(), reverse=False, noise=t(g["fwd_noise"]).cuda())
+            assert abs(float(nll) - float(g["fwd_nll"])) <= 2e-4 * max(1.0, abs(float(g["fwd_nll"])) / 100)
+        else:
+            lr_hat, z1, z2 = net(hr=hr, reverse=False)
+            assert maxdiff(z1, g["fwd_z1"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z1"]).max()))
+            assert maxdiff(z2, g["fwd_z2"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z2"]).max()))
+        assert maxdiff(lr_hat, g["fwd_lr"]) <= 1e-4
+        for i, k in enumerate(keys):
+            m = mods[k]
+            assert m.inited is True
+            assert maxdiff(m.bias.reshape(-1), g["an_bias_%d" % i]) <= 1e-5 * max(1.0, float(np.abs(g["an_bias_%d" % i]).max())), k
+            assert maxdiff(m.logs.reshape(-1), g["an_logs_%d" % i]) <= 1e-5, k
+        # second pass: nothing left to fit, same parameters -> same outputs (now possibly on the f16x3 kernels)
+        net.eval()
+        if cfg.sr:
+            lr2, nll2 = net(hr=hr, lr=t(g["lr"]).cuda(), reverse=False, noise=t(g["fwd_noise"]).cuda())
+            assert abs(float(nll2) - float(nll)) <= 1e-4 * max(1.0, abs(float(nll)) / 100)
+        else:
+            lr2, _, _ = net(hr=hr, reverse=False)
+        assert maxdiff(lr2, lr_hat) <= 1e-4
+    net.set_precision("exact")
+
+
+def test_actnorm_init_rules():
+    """eval() never initialises (ActNorms.py:31-32); a non-zero bias only flips ``inited`` (:33-35); the reverse
+    path refuses un-initialised layers in train() mode instead of guessing."""
+    from hcflow_amd import HCFlowNet_SR
+    cfg = preset("SR_4X_tiny")
+    p = cached_params("SR_4X_tiny", 11)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    net = net.to("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    hr = torch.rand(1, 3, 32, 32, generator=g).cuda()
+    lr = torch.rand(1, 3, 8, 8, generator=g).cuda()
+    an = [m for m in net.modules() if "ActNorm" in type(m).__name__]
+    before = [m.bias.detach().clone() for m in an]
+    with torch.no_grad():
+        net.eval()
+        net(hr=hr, lr=lr, reverse=False)
+        assert not any(m.inited for m in an)                       # eval: untouched, still un-initialised
+        net.train()
+        with pytest.raises(NotImplementedError):
+            net(lr=lr, eps_std=0.5, reverse=True)
+        net(hr=hr, lr=lr, reverse=False)                           # biases are non-zero: flags flip, values stay
+    assert all(m.inited for m in an)
+    assert all(torch.equal(m.bias, b) for m, b in zip(an, before))

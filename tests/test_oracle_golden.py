@@ -139,3 +139,38 @@ def test_rescale_forward_roundtrip(name):
         assert maxdiff(z2, g["fwd_z2"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z2"]).max()))
         rt = O.rescale_inverse(t(g["rt_lrq"]), p, cfg, 1.0, _eps(g, "rt"))
         assert maxdiff(rt, g["rt_out"]) <= 1e-4
+
+
+ANINIT = ["aninit_sr4_tiny", "aninit_sr8_tiny", "aninit_rescale_tiny"]
+
+
+def aninit_case(g):
+    """The fixture's setting: seeded weights, every ActNorm zeroed and awaiting its data-dependent init."""
+    cfg, p = params_for(g)
+    keys = [str(k) for k in g["an_keys"]]
+    p0 = dict(p)
+    for k in keys:
+        p0[k + ".bias"] = torch.zeros_like(p[k + ".bias"])
+        p0[k + ".logs"] = torch.zeros_like(p[k + ".logs"])
+    return cfg, p0, keys
+
+
+@pytest.mark.parametrize("name", ANINIT)
+def test_actnorm_data_init_pass(name):
+    """One train()-mode forward of the reference with un-initialised ActNorms (ActNorms.py:29-43): the oracle fits
+    the same bias / logs, in the same order, and produces the same outputs."""
+    g = load_golden(name)
+    cfg, p0, keys = aninit_case(g)
+    ip = O.InitParams(p0, keys)
+    if cfg.sr:
+        lr_hat, nll = O.sr_forward(t(g["hr"]), t(g["lr"]), ip, cfg, noise=t(g["fwd_noise"]))
+        assert abs(float(nll) - float(g["fwd_nll"])) <= 2e-4 * max(1.0, abs(float(g["fwd_nll"])) / 100)
+    else:
+        lr_hat, z1, z2 = O.rescale_forward(t(g["hr"]), ip, cfg)
+        assert maxdiff(z1, g["fwd_z1"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z1"]).max()))
+        assert maxdiff(z2, g["fwd_z2"]) <= 1e-4 * max(1.0, float(np.abs(g["fwd_z2"]).max()))
+    assert not ip.pending
+    assert maxdiff(lr_hat, g["fwd_lr"]) <= 1e-4
+    for i, k in enumerate(keys):
+        assert maxdiff(ip[k + ".bias"].reshape(-1), g["an_bias_%d" % i]) <= 1e-5 * max(1.0, float(np.abs(g["an_bias_%d" % i]).max())), k
+        assert maxdiff(ip[k + ".logs"].reshape(-1), g["an_logs_%d" % i]) <= 1e-5, k
