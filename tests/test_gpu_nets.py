@@ -226,3 +226,76 @@ def test_actnorm_init_rules():
         net(hr=hr, lr=lr, reverse=False)                           # biases are non-zero: flags flip, values stay
     assert all(m.inited for m in an)
     assert all(torch.equal(m.bias, b) for m, b in zip(an, before))
+
+
+# ---- BASELINE.json's full-size configurations, through size-independent properties ------------------------------
+def _full_net(name, seed):
+    cfg = preset(name)
+    return cfg, build_net(cfg, cached_params(name, seed))
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+def test_config2_full_size_batch_independence(precision):
+    """Config 2 (SR x4, B = 16, LR 160^2 -> HR 640^2, tau = 0.8): every op of the path is per-sample, so sample k
+    of the batched run must equal the same sample run alone (same injected eps) bit for bit."""
+    cfg, net = _full_net("SR_DF2K_4X", 1234)
+    g = torch.Generator().manual_seed(77)
+    B, h = 16, 160
+    lr = torch.rand(B, 3, h, h, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, h, h)]
+    net.set_precision(precision)
+    try:
+        with torch.no_grad():
+            full = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            assert bool(torch.isfinite(full).all())
+            for k in (0, 9):
+                one = net.reverse_flow_diracLR(lr[k:k + 1], None, None, eps_std=0.8, eps=[e[k:k + 1] for e in eps], clamp=False)
+                assert torch.equal(one, full[k:k + 1]), k
+    finally:
+        net.set_precision("exact")
+
+
+def test_config3_face_x8_tau_sweep():
+    """Config 3 (Face x8, B = 32, LR 20^2 -> 160^2): tau = 0 is deterministic (z = mean) and independent of the
+    injected noise; across the tau sweep the f16x3 kernels stay within 1e-4 of the exact ones."""
+    cfg, net = _full_net("SR_CelebA_8X", 1234)
+    g = torch.Generator().manual_seed(78)
+    B, h = 32, 20
+    lr = torch.rand(B, 3, h, h, generator=g).cuda()
+    unit = [torch.randn(s, generator=g).cuda() for s in eps_shapes(cfg, B, h, h)]
+    with torch.no_grad():
+        a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.0, eps=[u * 0.0 for u in unit], clamp=False)
+        b = net.reverse_flow_diracLR(lr, None, None, eps_std=0.0, eps=None, clamp=False)
+        assert torch.equal(a, b)
+        for tau in (0.2, 0.6, 1.0):
+            eps = [u * tau for u in unit]
+            ex = net.reverse_flow_diracLR(lr, None, None, eps_std=tau, eps=eps, clamp=False)
+            net.set_precision("f16x3")
+            try:
+                fa = net.reverse_flow_diracLR(lr, None, None, eps_std=tau, eps=eps, clamp=False)
+            finally:
+                net.set_precision("exact")
+            assert bool(torch.isfinite(ex).all())
+            assert maxdiff(fa, ex) <= 1e-4 * max(1.0, float(ex.abs().max())), tau
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+def test_config4_rescaling_shard_roundtrip(precision):
+    """Config 4 (rescaling x4, 8 images of 640^2 per GPU): encode -> decode with the encoded latents reproduces the
+    HR batch (invertibility of the whole flow at full size), and the quantised-LR round trip the reference's test
+    loop runs (HCFlow_Rescaling_model.py:306-324) stays finite."""
+    cfg, net = _full_net("Rescaling_DF2K_4X", 1234)
+    g = torch.Generator().manual_seed(79)
+    hr = torch.rand(8, 3, 640, 640, generator=g).cuda()
+    net.set_precision(precision)
+    try:
+        with torch.no_grad():
+            lr_raw, z1, z2 = net.normal_flow_diracLR(hr, clamp=False)
+            back = net.reverse_flow_diracLR(lr_raw, None, None, eps_std=1.0, eps=[z2, z1], clamp=False)
+            assert maxdiff(back, hr) <= 5e-4
+            lr_hat, _, _ = net(hr=hr, reverse=False)
+            lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.
+            rt = net(lr=lrq, eps_std=1.0, reverse=True)
+            assert bool(torch.isfinite(rt).all()) and float(rt.min()) >= 0.0 and float(rt.max()) <= 1.0
+    finally:
+        net.set_precision("exact")
