@@ -25,7 +25,7 @@ SYMBOLS = [
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
-    "hcf_actnorm_init_request", "hcf_get_param",
+    "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
 ]
 
 
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
     lib.hcf_get_param.argtypes = [vp, C.c_char_p, fp, i64]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,
                                   i32, i32, i32, fp, f32, fp, f32, fp, vp]
+    lib.hcf_op_conv2d_backward.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, i32, i32,
+                                           fp, C.POINTER(fp), fp, fp, vp]
     lib.hcf_op_squeeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
     lib.hcf_op_unsqueeze2d.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp]
     lib.hcf_op_step_inverse.argtypes = [fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, fp, fp, fp, vp]

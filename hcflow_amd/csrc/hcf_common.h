@@ -68,6 +68,19 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 // fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
 
+// ---- conv weight gradient (training path) ---------------------------------------------------------------------
+// dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)
+struct WgradArgs {
+  View src[kMaxSrc];       // the forward conv's input windows (cat order), optional nearest upsample
+  int nsrc;
+  View g;                  // gradient w.r.t. the conv's pre-activation output, n = cout
+  int B, H, W;
+  int taps;                // 9 (3x3, pad 1) or 1
+  float* dw;               // [cout][cin_total][taps], accumulated (caller zero-initialises)
+  int cin_total, tpb;      // set by the launcher
+};
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);
+
 // ---- flow-step glue --------------------------------------------------------------------------
 enum { CPL_AFFINE = 0, CPL_SHIFT3 = 1 };
 
@@ -130,5 +143,7 @@ int launch_reduce_partials(const float* partial, int stride, int n, int B, doubl
 int launch_fill(float* p, size_t n, float v, hipStream_t st);
 // out[0..n) = per-channel sum, out[n..2n) = per-channel sum of squares over all B*H*W pixels of the window (double)
 int launch_channel_stats(View v, int B, int H, int W, double* out, hipStream_t st);
+// backward of the nearest upsample: out[b, y, x, c] (+)= sum over the 2^up x 2^up block of `in` ([B, Ho << up, Wo << up])
+int launch_sumpool(View in, View out, int B, int Ho, int Wo, int up, int accumulate, hipStream_t st);
 
 }  // namespace hcf

@@ -1,0 +1,169 @@
+// Weight gradient of the fused 3x3 / 1x1 convolution (training path) for gfx950.
+//
+//   dW[oc][ic][tap] += sum over (b, y, x) of  X[b, y + dy - pad, x + dx - pad, ic] * G[b, y, x, oc]
+//
+// X is the forward input (the same <= 3 NHWC source windows, optionally read through a nearest upsample), G the
+// gradient w.r.t. the conv's pre-activation output. Per tap this is a GEMM with M = input channels, N = output
+// channels, K = pixels, run on v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation):
+//   block  = 4 waves, one (32 input channels) x (32 output channels) tile of dW, all taps;
+//   K loop = the block walks `tpb` pixel tiles of 8 x 32; per tile the 10 x 34 halo of X (32 channels) and the
+//            8 x 32 tile of G (32 channels) are staged in LDS as [pixel][32 ch] (conflict-free ds_read_b32: lane i
+//            reads channel i), wave w owns tile rows {2w, 2w+1} = 32 K-steps of two pixels, 9 MFMAs each (one per
+//            tap: the A operand is the same halo tile shifted by the tap);
+//   end    = the 4 waves' accumulators are summed through LDS and added to dW with fp32 atomics (several blocks
+//            share a dW tile; the order of those atomics is the only run-to-run non-determinism).
+#include "hcf_common.h"
+
+namespace hcf {
+namespace wgrad {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 32;
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
+  __shared__ __attribute__((aligned(16))) float xs[HP * 32];
+  __shared__ __attribute__((aligned(16))) float gs[TH * TW * 32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = a.B * tiles_x * tiles_y;
+
+  // which 32-channel block of which source window
+  int blk = blockIdx.y, si = 0;
+  for (; si < a.nsrc; ++si) {
+    const int nb = (a.src[si].n + 31) >> 5;
+    if (blk < nb) break;
+    blk -= nb;
+  }
+  const View sv = a.src[si];
+  const int ic0 = blk * 32;                       // first channel of the block inside the window
+  const int icn = min(32, sv.n - ic0);            // valid channels
+  int ic_base = 0;                                // channel offset of this window in the conv's input (cat order)
+  for (int j = 0; j < si; ++j) ic_base += a.src[j].n;
+  const int oc0 = blockIdx.z * 32;
+  const int ocn = min(32, a.g.n - oc0);
+  const int up = sv.up, Hs = H >> up, Ws = W >> up;
+  const bool vecx = (((sv.cs | (sv.c0 + ic0)) & 3) == 0) && ((reinterpret_cast<uintptr_t>(sv.p) & 15) == 0);
+  const bool vecg = (((a.g.cs | (a.g.c0 + oc0)) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.g.p) & 15) == 0);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int t0 = blockIdx.x * a.tpb, t1 = min(ntiles, t0 + a.tpb);
+  for (int tile = t0; tile < t1; ++tile) {
+    const int txb = tile % tiles_x, tyb = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = txb * TW, y0 = tyb * TH;
+    __syncthreads();                              // the previous tile's fragments have been read
+    // ---- stage X halo: HP pixels x 8 float4
+    for (int q = tid; q < HP * 8; q += 256) {
+      const int hp = q >> 3, c4 = (q & 7) * 4;
+      const int hy = hp / HW, hx = hp - hy * HW;
+      const int y = y0 + hy - PAD, x = x0 + hx - PAD;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y >= 0 && y < H && x >= 0 && x < W && c4 < icn) {
+        const float* p = sv.p + ((size_t)((size_t)b * Hs + (y >> up)) * Ws + (x >> up)) * sv.cs + sv.c0 + ic0 + c4;
+        if (vecx && c4 + 4 <= icn) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          v.x = p[0];
+          if (c4 + 1 < icn) v.y = p[1];
+          if (c4 + 2 < icn) v.z = p[2];
+          if (c4 + 3 < icn) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(xs + hp * 32 + c4) = v;
+    }
+    // ---- stage G: 256 pixels x 8 float4
+    for (int q = tid; q < TH * TW * 8; q += 256) {
+      const int px = q >> 3, c4 = (q & 7) * 4;
+      const int y = y0 + (px >> 5), x = x0 + (px & 31);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y < H && x < W && c4 < ocn) {
+        const float* p = a.g.p + ((size_t)((size_t)b * H + y) * W + x) * a.g.cs + a.g.c0 + oc0 + c4;
+        if (vecg && c4 + 4 <= ocn) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          v.x = p[0];
+          if (c4 + 1 < ocn) v.y = p[1];
+          if (c4 + 2 < ocn) v.z = p[2];
+          if (c4 + 3 < ocn) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(gs + px * 32 + c4) = v;
+    }
+    __syncthreads();
+    // ---- 2 rows x 16 pixel pairs per wave
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr;
+#pragma unroll 4
+      for (int pp = 0; pp < 16; ++pp) {
+        const int xx = 2 * pp + half;
+        const float bg = gs[(row * TW + xx) * 32 + li];                  // B[k = half][n = li]
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
+          const float ax = xs[((row + dy) * HW + xx + dx) * 32 + li];    // A[m = li][k = half]
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bg, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- cross-wave reduction through LDS, then atomics into dW[oc][ic][tap]
+  float* red = xs;                                 // 4 waves x 1024 floats
+#pragma unroll 1
+  for (int t = 0; t < TAPS; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;                  // input channel within the block
+      red[wave * 1024 + m * 32 + li] = acc[t][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) {
+      const int m = e >> 5, n = e & 31;
+      if (m < icn && n < ocn) {
+        const float s = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+        atomicAdd(a.dw + ((size_t)(oc0 + n) * a.cin_total + ic_base + ic0 + m) * TAPS + t, s);
+      }
+    }
+  }
+}
+
+}  // namespace wgrad
+
+int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
+  if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1) return HCF_ERR_ARG;
+  WgradArgs a = a0;
+  int nicb = 0, cin = 0;
+  for (int i = 0; i < a.nsrc; ++i) {
+    if ((a.H >> a.src[i].up) << a.src[i].up != a.H || (a.W >> a.src[i].up) << a.src[i].up != a.W) return HCF_ERR_ARG;
+    nicb += (a.src[i].n + 31) >> 5;
+    cin += a.src[i].n;
+  }
+  a.cin_total = cin;
+  const int tiles = a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8);
+  const int pairs = nicb * ((a.g.n + 31) >> 5);
+  // enough blocks to fill 256 CUs x 2, but as few dW-tile sharers (atomics) as that allows
+  int nblk_x = (1024 + pairs - 1) / pairs;
+  if (nblk_x > tiles) nblk_x = tiles;
+  if (nblk_x < 1) nblk_x = 1;
+  a.tpb = (tiles + nblk_x - 1) / nblk_x;
+  nblk_x = (tiles + a.tpb - 1) / a.tpb;
+  const dim3 grid((unsigned)nblk_x, (unsigned)nicb, (unsigned)((a.g.n + 31) >> 5));
+  if (a.taps == 9) hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<9>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+}  // namespace hcf

@@ -446,6 +446,26 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(View v, long long np
   }
 }
 
+// ---- backward of the nearest upsample folded into conv addressing: out[y, x] (+)= sum of the 2^up x 2^up block -----
+__global__ __launch_bounds__(256) void sumpool_kernel(View in, View out, int Ho, int Wo, int up, int accumulate) {
+  const int n = out.n;
+  const long long total = (long long)gridDim.y * Ho * Wo * n;      // gridDim.y = B
+  (void)total;
+  const int b = blockIdx.y;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)Ho * Wo * n) return;
+  const int c = (int)(e % n);
+  const long long pix = e / n;
+  const int x = (int)(pix % Wo), y = (int)(pix / Wo);
+  const int f = 1 << up, Wi = Wo << up, Hi = Ho << up;
+  float s = 0.f;
+  for (int i = 0; i < f; ++i)
+    for (int j = 0; j < f; ++j)
+      s += in.p[((size_t)((size_t)b * Hi + (y << up) + i) * Wi + (x << up) + j) * in.cs + in.c0 + c];
+  float* o = out.p + ((size_t)((size_t)b * Ho + y) * Wo + x) * out.cs + out.c0 + c;
+  *o = accumulate ? *o + s : s;
+}
+
 int launch_nchw_to_nhwc(const float* src, View dst, int B, int C, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, pix_grid(B, H, W), dim3(256), 0, st, src, dst, C, H * W);
   HCF_RET();
@@ -514,6 +534,14 @@ int launch_channel_stats(View v, int B, int H, int W, double* out, hipStream_t s
   const long long npix = (long long)B * H * W;
   const int ppb = 4096;
   hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, st, v, npix, ppb, out);
+  HCF_RET();
+}
+
+int launch_sumpool(View in, View out, int B, int Ho, int Wo, int up, int accumulate, hipStream_t st) {
+  if (in.n != out.n || up < 0 || up > 4) return HCF_ERR_ARG;
+  const long long per = (long long)Ho * Wo * out.n;
+  hipLaunchKernelGGL(sumpool_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, in, out, Ho, Wo, up,
+                     accumulate);
   HCF_RET();
 }
 

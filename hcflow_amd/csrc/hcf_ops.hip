@@ -163,6 +163,106 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
   return rc;
 }
 
+// Transposed weights for the data gradient of source window [off, off + n) of a conv with weight w [cout][cin][k][k]:
+// wt[ic][oc][t] = w[oc][off + ic][taps - 1 - t]  (a 3x3 "same" conv of the output gradient with the flipped kernel)
+static void transpose_weights(const float* w, int cin, int cout, int taps, int off, int n, std::vector<float>& wt) {
+  wt.assign((size_t)n * cout * taps, 0.f);
+  for (int ic = 0; ic < n; ++ic)
+    for (int oc = 0; oc < cout; ++oc)
+      for (int t = 0; t < taps; ++t)
+        wt[((size_t)ic * cout + oc) * taps + t] = w[((size_t)oc * cin + off + ic) * taps + (taps - 1 - t)];
+}
+
+// Gradients of y = conv2d(cat(up(src_i)), w) + bias w.r.t. the sources, the weight and the bias, given
+// g = dL/dy (torch.autograd of F.conv2d; the training path of SURVEY.md 8f rank 1). dsrc[i] may be NULL.
+int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const int32_t* src_up, int32_t n_src,
+                           int32_t B, int32_t H, int32_t W, const float* w, int32_t cout, int32_t k, const float* g,
+                           float* const* dsrc, float* dw, float* dbias, hcf_stream_t stream) {
+  if (!src || !src_c || !w || !g || n_src < 1 || n_src > kMaxSrc || (k != 1 && k != 3) || cout < 1 || cout > 96)
+    return HCF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Tmp t;
+  int rc = HCF_OK;
+  const int taps = k * k;
+  int cin = 0;
+  for (int i = 0; i < n_src; ++i) cin += src_c[i];
+  View gv = nhwc_from_nchw(t, g, B, cout, H, W, st, rc);
+  if (!t.ok) return HCF_ERR_NOMEM;
+  // ---- data gradients: one conv of g per <= 64-channel block of each source window
+  int off = 0;
+  for (int i = 0; i < n_src && rc == HCF_OK; ++i) {
+    const int up = src_up ? src_up[i] : 0, n = src_c[i];
+    if (dsrc && dsrc[i]) {
+      float* full = t.dev((size_t)B * H * W * ru4(n));
+      if (!t.ok) return HCF_ERR_NOMEM;
+      for (int c0 = 0; c0 < n && rc == HCF_OK; c0 += 64) {
+        const int nb = std::min(64, n - c0);
+        std::vector<float> wt;
+        transpose_weights(w, cin, cout, taps, off + c0, nb, wt);
+        ConvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src[0] = gv; a.src[1] = gv; a.src[2] = gv;
+        a.nsrc = 1;
+        a.B = B; a.H = H; a.W = W;
+        std::vector<float> hb(64, 0.f), hs(64, 1.f);
+        a.bias = t.up(hb);
+        a.scale = t.up(hs);
+        a.act = ACT_NONE;
+        a.out = mkview(full, ru4(n), c0, nb);
+        a.res1 = mkview(nullptr, 0, 0, 0);
+        a.res2 = mkview(nullptr, 0, 0, 0);
+        int one = cout;
+        rc = pack_and_launch(t, a, wt.data(), cout, nb, k, &one, 1, st);
+      }
+      if (rc != HCF_OK) break;
+      View fv = mkview(full, ru4(n), 0, n);
+      if (up > 0) {
+        float* low = t.dev((size_t)B * (H >> up) * (W >> up) * ru4(n));
+        if (!t.ok) return HCF_ERR_NOMEM;
+        View lv = mkview(low, ru4(n), 0, n);
+        rc = launch_sumpool(fv, lv, B, H >> up, W >> up, up, 0, st);
+        if (rc == HCF_OK) rc = launch_nhwc_to_nchw(lv, dsrc[i], B, n, H >> up, W >> up, 0, st);
+      } else {
+        rc = launch_nhwc_to_nchw(fv, dsrc[i], B, n, H, W, 0, st);
+      }
+    }
+    off += n;
+  }
+  // ---- weight gradient
+  if (rc == HCF_OK && dw) {
+    WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    for (int i = 0; i < n_src; ++i) {
+      const int up = src_up ? src_up[i] : 0;
+      wa.src[i] = nhwc_from_nchw(t, src[i], B, src_c[i], H >> up, W >> up, st, rc);
+      wa.src[i].up = up;
+    }
+    wa.nsrc = n_src;
+    wa.g = gv;
+    wa.B = B; wa.H = H; wa.W = W; wa.taps = taps;
+    const size_t nw = (size_t)cout * cin * taps;
+    wa.dw = t.dev(nw);
+    if (!t.ok) return HCF_ERR_NOMEM;
+    if (hipMemsetAsync(wa.dw, 0, nw * sizeof(float), st) != hipSuccess) return HCF_ERR_HIP;
+    if (rc == HCF_OK) rc = launch_conv_wgrad(wa, st);
+    if (rc == HCF_OK && hipMemcpyAsync(dw, wa.dw, nw * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) rc = HCF_ERR_HIP;
+  }
+  // ---- bias gradient: per-channel sums of g
+  std::vector<double> hs;
+  if (rc == HCF_OK && dbias) {
+    double* sd = (double*)t.dev(4 * (size_t)cout);
+    if (!t.ok) return HCF_ERR_NOMEM;
+    hs.resize(2 * (size_t)cout);
+    rc = launch_channel_stats(gv, B, H, W, sd, st);
+    if (rc == HCF_OK && hipMemcpyAsync(hs.data(), sd, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, st) != hipSuccess)
+      rc = HCF_ERR_HIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) return HCF_ERR_HIP;
+  if (rc == HCF_OK && dbias)
+    for (int c = 0; c < cout; ++c) dbias[c] = (float)hs[c];
+  return rc;
+}
+
 // shader clock (MHz) observed inside the last hcf_bench_conv kernels (s_memtime / s_memrealtime)
 double hcf_debug_last_clock_mhz(void) { return g_last_clock_mhz; }
 // timing ablations of the f16x3 kernel (tools/conv_bench.py --ablate); 0 = off

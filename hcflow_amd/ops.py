@@ -65,6 +65,32 @@ def conv2d(srcs: Sequence[torch.Tensor], weight: torch.Tensor, bias=None, scale=
     return out
 
 
+def conv2d_backward(srcs: Sequence[torch.Tensor], weight: torch.Tensor, grad_out: torch.Tensor,
+                    ups: Optional[Sequence[int]] = None, need_input_grads: bool = True):
+    """torch.autograd of ``F.conv2d(cat(upsampled srcs), weight, bias, 1, k // 2)``: returns
+    ([d srcs] or None, d weight (CPU), d bias (CPU))."""
+    lib = _lib.load()
+    srcs = [_dev(s) for s in srcs]
+    g = _dev(grad_out)
+    n = len(srcs)
+    ups = list(ups) if ups is not None else [0] * n
+    B, cout, H, W = g.shape
+    co, cin, k, _ = weight.shape
+    assert co == cout and sum(s.shape[1] for s in srcs) == cin
+    ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    cs = (C.c_int32 * n)(*[s.shape[1] for s in srcs])
+    us = (C.c_int32 * n)(*ups)
+    wh, wp = _host(weight)
+    dsrcs = [torch.empty_like(s) for s in srcs] if need_input_grads else None
+    dptrs = (C.c_void_p * n)(*([d.data_ptr() for d in dsrcs] if dsrcs else [None] * n))
+    dw = torch.empty(cout, cin, k, k, dtype=torch.float32)
+    db = torch.empty(cout, dtype=torch.float32)
+    rc = lib.hcf_op_conv2d_backward(ptrs, cs, us, n, B, H, W, wp, cout, k, g.data_ptr(), dptrs,
+                                    C.c_void_p(dw.data_ptr()), C.c_void_p(db.data_ptr()), _stream(g))
+    _lib.check(rc, None, "hcf_op_conv2d_backward")
+    return dsrcs, dw, db
+
+
 def squeeze2d(x: torch.Tensor, haar: bool = False) -> torch.Tensor:
     lib = _lib.load()
     x = _dev(x)

@@ -166,6 +166,17 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
                   int32_t H, int32_t W, const float* w, const float* bias, const float* scale, int32_t cout, int32_t k,
                   int32_t act, const float* res1, float rs1, const float* res2, float rs2, float* out,
                   hcf_stream_t stream);
+
+/* Backward of hcf_op_conv2d without epilogue (torch.autograd of F.conv2d(cat(up(src_i)), w, bias, 1, k/2); the
+ * reference reaches it through loss.backward() in HCFlow_SR_model.optimize_parameters, HCFlow_SR_model.py:195-202):
+ * g = dL/dy, device [B,cout,H,W]. dsrc[i] (device [B, src_c[i], H >> up, W >> up]) may be NULL; dw is a HOST buffer
+ * [cout, cin, k, k], dbias a HOST buffer [cout]; either may be NULL. Data gradients run on the forward conv
+ * kernels with transposed / flipped weights (process-wide op precision), the weight gradient on the fp32 MFMA
+ * kernel of hcf_conv_wgrad.hip (accumulated with fp32 atomics). */
+int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const int32_t* src_up, int32_t n_src,
+                           int32_t B, int32_t H, int32_t W, const float* w, int32_t cout, int32_t k, const float* g,
+                           float* const* dsrc, float* dw, float* dbias, hcf_stream_t stream);
+
 /* Basic.squeeze2d / unsqueeze2d factor 2 (Basic.py:127-157) and HaarDownsampling (Basic.py:470-487) */
 int hcf_op_squeeze2d(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t haar, hcf_stream_t stream);
 int hcf_op_unsqueeze2d(const float* x, float* out, int32_t B, int32_t C4, int32_t H, int32_t W, int32_t haar, hcf_stream_t stream);
