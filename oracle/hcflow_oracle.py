@@ -316,8 +316,12 @@ def gaussian_sample(mean, logs, eps_std, eps=None):
 
 
 def quantize(x):
-    """Basic.Quant.forward (Basic.py:187-191): round(clamp(x,0,1) * 255) / 255."""
-    return (torch.clamp(x, 0, 1) * 255.).round() / 255.
+    """Basic.Quant (Basic.py:186-196): forward round(clamp(x,0,1) * 255) / 255, backward the identity
+    (straight-through, also outside [0, 1])."""
+    q = (torch.clamp(x, 0, 1) * 255.).round() / 255.
+    if x.requires_grad:
+        return x + (q - x).detach()
+    return q
 
 
 # ------------------------------------------------------------------ conditional flow

@@ -194,6 +194,46 @@ def gen_aninit_fixture(name, preset_name, ref_sr, ref_rs, B, h, w, seed):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def grad_digest(g, i):
+    """Three numbers per gradient tensor: l2 norm, sum, and a seeded random projection."""
+    g = np.asarray(g, dtype=np.float64).reshape(-1)
+    r = np.random.RandomState(1000 + i).standard_normal(g.size)
+    return float(np.sqrt((g * g).sum())), float(g.sum()), float((g * r).sum())
+
+
+def gen_grad_fixture(name, preset_name, ref_sr, B, h, w, seed):
+    """d nll / d parameters of ONE reference NLL step (HCFlow_SR_model.py:195-199: nll of netG(hr, lr), backward)
+    on our seeded weights; digests for every tensor, full gradients for the small ones."""
+    cfg = preset(preset_name)
+    net, params = build(ref_sr, cfg, seed)
+    net.train()                                   # ActNorms are marked inited: train() == eval() arithmetic
+    g = torch.Generator().manual_seed(seed + 41)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=g)
+    lr = torch.rand(B, 3, h, w, generator=g)
+    with Capture() as cap:
+        lr_hat, nll = net(hr=hr, lr=lr, reverse=False)
+    nll.backward()
+    out = {"preset": preset_name, "seed": seed, "hr": np_(hr), "lr": np_(lr), "fwd_noise": np_(cap.rand[0]),
+           "fwd_nll": np.float64(float(nll)), "fwd_lr": np_(lr_hat)}
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    dig, nfull = [], 0
+    for i, (k, prm) in enumerate(net.named_parameters()):
+        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+        dig.append(grad_digest(gr, i))
+        if gr.size <= 2304:
+            out["g_%d" % i] = gr
+            nfull += 1
+    keys = [k for k, _ in net.named_parameters()]
+    assert keys == [k for k, _, _ in param_spec(cfg)]
+    out["gdigest"] = np.array(dig, dtype=np.float64)
+    print("  %s nll %.6f: %d tensors, %d stored in full, |g| range [%.3e, %.3e]" % (
+        name, float(nll), len(dig), nfull, min(d[0] for d in dig), max(d[0] for d in dig)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def gen_op_fixture(ref_sr, ref_rs):
     """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
     from models.modules import Basic, thops
@@ -306,6 +346,11 @@ def main():
         gen_aninit_fixture("aninit_sr8_tiny", "SR_8X_tiny", ref_sr, ref_rs, B=2, h=5, w=6, seed=32)
         gen_aninit_fixture("aninit_rescale_tiny", "Rescaling_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=33)
         if only == "aninit":
+            return
+    if only in ("all", "grad"):
+        gen_grad_fixture("grad_sr4_tiny", "SR_4X_tiny", ref_sr, B=2, h=10, w=12, seed=41)
+        gen_grad_fixture("grad_sr8_tiny", "SR_8X_tiny", ref_sr, B=2, h=5, w=6, seed=42)
+        if only == "grad":
             return
     gen_op_fixture(ref_sr, ref_rs)
     # reduced-depth nets with the real channel widths, odd-ish spatial sizes, B=2
