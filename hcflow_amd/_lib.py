@@ -26,6 +26,7 @@ SYMBOLS = [
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
+    "hcf_train_forward_sr", "hcf_train_backward",
 ]
 
 
@@ -87,6 +88,8 @@ def load() -> C.CDLL:
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
     lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.hcf_train_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
+    lib.hcf_train_backward.argtypes = [vp, f32, fp, i64, vp]
     lib.hcf_actnorm_init_request.argtypes = [vp, C.POINTER(C.c_char_p), i32]
     lib.hcf_get_param.argtypes = [vp, C.c_char_p, fp, i64]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,

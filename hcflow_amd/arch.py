@@ -228,6 +228,48 @@ class FlowNet(nn.Module):
         print('shapes:', self.output_shapes)      # FlowNet_SR_x4.py:71 (part of the boundary's observable behaviour)
 
 
+# ------------------------------------------------------------------ NLL training step (autograd bridge)
+class _SRNLLStep(torch.autograd.Function):
+    """``_, nll = netG(hr=, lr=, reverse=False)`` with gradients (HCFlow_SR_model.py:195-199): the engine keeps the
+    intermediate tensors of the forward pass in HBM (hcf_train_forward_sr) and produces d nll / d parameters for the
+    whole net in one call (hcf_train_backward); this Function only hands the flat gradient buffer to autograd."""
+
+    @staticmethod
+    def forward(ctx, module, hr, lr, noise, *params):
+        dev = hr.device
+        eng, idx = module._engine_for(dev)
+        B, _, H, W = hr.shape
+        s = module.cfg.scale
+        out_lr = torch.empty(B, 3, H // s, W // s, device=dev)
+        nll = torch.empty(1, device=dev)
+        logdet = torch.empty(B, device=dev)
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_train_forward_sr(eng.handle, hr.data_ptr(), lr.data_ptr(), noise.data_ptr(),
+                                              out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(), B, H, W,
+                                              module._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_train_forward_sr")
+        ctx.eng, ctx.idx = eng, idx
+        ctx.keep = (hr, lr, noise)                       # the engine's tape holds raw pointers to these
+        ctx.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
+        ctx.mark_non_differentiable(out_lr, logdet)
+        return out_lr, nll.view(()), logdet
+
+    @staticmethod
+    def backward(ctx, g_lr, g_nll, g_logdet):
+        eng, idx = ctx.eng, ctx.idx
+        total = sum(n for _, n, _ in ctx.meta)
+        flat = torch.empty(total, device=ctx.keep[0].device, dtype=torch.float32)
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_train_backward(eng.handle, float(g_nll), flat.data_ptr(), total,
+                                            C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+        _lib.check(rc, eng.handle, "hcf_train_backward")
+        grads, off = [], 0
+        for shape, n, need in ctx.meta:
+            grads.append(flat[off:off + n].view(shape) if need else None)
+            off += n
+        return (None, None, None, None) + tuple(grads)
+
+
 # ------------------------------------------------------------------ engine-backed top modules
 class _EngineModule(nn.Module):
     """Shared plumbing: parameter upload / repack tracking and raw-pointer calls into the C ABI."""
@@ -275,11 +317,15 @@ class _EngineModule(nn.Module):
             ent["stamp"] = stamp
         return ent["engine"], idx
 
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def _check_inference(self, reverse=False):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if self._wants_grad():
             raise NotImplementedError(
-                "hcflow_amd round 1 implements the forward/inverse inference path; the backward pass "
-                "(train_HCFlow.py optimize_parameters) is SURVEY.md section 8f rank 1. Call under torch.no_grad().")
+                "hcflow_amd builds the backward pass of the SR NLL objective (netG(hr=, lr=, reverse=False)); "
+                "gradients through %s are not built yet (SURVEY.md section 8f). Call under torch.no_grad()."
+                % ("the reverse (sampling) path" if reverse else "this forward path"))
         if self.training and reverse and self._pending_actnorms():
             raise NotImplementedError(
                 "un-initialised ActNorm layers in train() mode on the REVERSE path: the reference would fit them to "
@@ -373,7 +419,10 @@ class HCFlowNet_SR(_EngineModule):
 
     def normal_flow_diracLR(self, hr, lr, u=None, step=None, training=True, noise=None, return_internals=False):
         """hr -> (clamp(LR^), nll)   (HCFlowNet_SR_arch.py:47-67). ``noise``: optional injected U[0,1)
-        tensor replacing the internal torch.rand draw (:52)."""
+        tensor replacing the internal torch.rand draw (:52). With autograd enabled on trainable parameters the
+        pass runs through the engine's taped training path and ``nll.backward()`` works (HCFlow_SR_model.py:195-199)."""
+        if self._wants_grad() and not return_internals:
+            return self._normal_flow_train(hr, lr, noise)
         self._check_inference()
         dev = next(self.parameters()).device
         eng, idx = self._engine_for(dev)
@@ -399,6 +448,21 @@ class HCFlowNet_SR(_EngineModule):
         if return_internals:
             return out_lr, nll[0], logdet, zraw
         return out_lr, nll[0]
+
+    def _normal_flow_train(self, hr, lr, noise):
+        dev = next(self.parameters()).device
+        assert lr is not None, "the NLL objective needs lr"
+        hr, lr = self._prep(hr, dev), self._prep(lr, dev)
+        if noise is None:
+            noise = torch.rand(hr.shape, device=dev)
+        noise = self._prep(noise, dev)
+        if self.training and self._pending_actnorms():
+            # the reference fits un-initialised ActNorms inside this very forward (ActNorms.py:78-80, no_grad): do
+            # that with one statistics pass on the same batch / noise, then run the differentiable pass
+            with torch.no_grad():
+                self.normal_flow_diracLR(hr, lr, noise=noise)
+        out_lr, nll, _ = _SRNLLStep.apply(self, hr, lr, noise, *list(self.parameters()))
+        return out_lr, nll
 
     def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):
         """lr (+ sampled z) -> clamp(HR)   (HCFlowNet_SR_arch.py:70-75)."""

@@ -98,6 +98,7 @@ struct StepArgs {
   const float* an_mul;   // [C]  exp(-logs) (inverse) or exp(logs) (forward)
   float* partial;        // forward couple: per-block partial sums of logscale, [B][nblk]; else nullptr
   int partial_stride;    // floats between consecutive samples in `partial`
+  View aux;              // forward head, training tape: also store the ActNorm output (input of W); p == nullptr: no
 };
 
 int launch_step_tail_inv(const StepArgs& a, hipStream_t st);     // coupling^-1, W^-1, actnorm^-1
@@ -105,6 +106,53 @@ int launch_step_head_fwd(const StepArgs& a, hipStream_t st);     // actnorm, W  
 int launch_step_couple_fwd(const StepArgs& a, hipStream_t st);   // coupling (in place capable) + sum logscale
 int step_blocks_per_sample(int H, int W);
 int step_cmax(int C);   // register-array bucket (8/12/24/48) used by the step kernels; -1 if C > 48
+
+// ---- backward kernels of the training path (hcf_train.hip) ---------------------------------
+// Backward of the fused conv epilogue  y = res2 + rs2 * (res1 + rs1 * act((acc + bias) * scale)):
+//   g2 += gy ;  g1 += gy * rs2 ;  dz = gy * rs2 * rs1 * act'(y) ;  gpre = dz * scale  (= dL/d acc)
+//   sum_pre[c] += sum_pixels gpre          (conv bias / ActNorm bias / Conv2dZeros bias gradient)
+//   sum_zy[c]  += zy_mult * sum_pixels dz * y   (ActNorm logs: 1, Conv2dZeros logs: 3; act in {none, relu} there)
+struct EpiBwdArgs {
+  int B, H, W;
+  View gy, y;              // n = cout; y is read only when act != none or sum_zy != nullptr
+  const float* scale;      // [npad] forward epilogue scale
+  int act;
+  float rs1, rs2;          // as in the forward call (ignored for a missing residual)
+  int has1, has2;          // the forward conv had res1 / res2 (rs1 / rs2 are meaningful)
+  View g1, g2;             // gradient buffers of res1 / res2 (p may be nullptr: that gradient is not needed)
+  View gpre;
+  float* sum_pre;          // nullable
+  float* sum_zy;           // nullable
+  float zy_mult;
+};
+int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st);
+
+struct StepBwdArgs {
+  int B, H, W, C, ns, mode;
+  // coupling backward: (gzout, zout, h) -> gzb (=), gh (=)
+  View gzout, zout, h, gzb, gh;
+  float gobj;              // dL/d(objective) of every sample (the sum-of-logscale term feeds the log-det)
+  // head backward: (gzb, za) -> gzin (=), sums for ActNorm bias / logs
+  View za, gzin;
+  const float* matT;       // [CMAX][CMAX] W^T (row c = column c of W) or nullptr (no permutation)
+  const float* an_mul;     // exp(logs)
+  float* g_bias;           // [C] +=
+  float* g_logs;           // [C] +=
+};
+int launch_step_couple_bwd(const StepBwdArgs& a, hipStream_t st);
+int launch_step_head_bwd(const StepBwdArgs& a, hipStream_t st);
+
+struct PriorBwdArgs {
+  int B, H, W, C;          // C = channels of the latent; h has 2C (mean = h[0::2], logs = h[1::2])
+  View a, h, ga, gh;       // ga (=), gh (=)
+  float gobj;
+};
+int launch_gauss_logp_bwd(const PriorBwdArgs& a, hipStream_t st);
+// d/dz of logp(lr; mean := Quant(z), logs = -6) with the straight-through Quant: gz += gobj * (lr - q(z)) * e^12
+int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, int W, float gobj, hipStream_t st);
+int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st);      // out += alpha * in
+int launch_add_const(float* p, size_t n, float v, hipStream_t st);                             // p[i] += v
+int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st);              // y += alpha * x
 
 // ---- Gaussian prior / misc elementwise -------------------------------------------------------
 struct GaussArgs {

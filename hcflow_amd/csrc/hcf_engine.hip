@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>
@@ -44,6 +45,11 @@ struct Conv {
   float* wpack16 = nullptr;                                     // device, f16x3 split pack (or null: exact only)
   double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
   std::string an_key;                                           // Basic.Conv2d: prefix of its ActNorm ("....conv1.actnorm")
+  // training path: state_dict keys of the parameters behind this layer and what the epilogue sums mean for them
+  std::string wkey, bkey, lkey;                                 // weight; bias (sum of d pre-activation); logs (or "")
+  float l_mult = 0.f;                                           // d logs = l_mult * sum(dz * y): ActNorm 1, Conv2dZeros 3
+  struct TPack { float *wpack = nullptr, *wpack16 = nullptr; int nchunk = 0, npad = 0, src = 0, c0 = 0, n = 0; };
+  std::vector<TPack> tpacks;                                    // data-gradient packs: (source window, <= 64-ch block)
 };
 
 struct Step {
@@ -55,6 +61,9 @@ struct Step {
   double ld_const = 0;              // per pixel: sum(actnorm logs) + slogdet(W)
   double lad = 0;                   // slogdet(W) alone
   std::string an_key;               // prefix of the step's ActNorm ("....actnorm")
+  std::string wkey;                 // "....permute.weight" (or "")
+  float *mat_fwdT = nullptr;        // training: W^T padded [cmax][cmax] (gza = W^T gzb)
+  float *winvT = nullptr;           // training: W^-T, [C][C] unpadded (d slogdet / dW)
 };
 
 struct Rdb { Conv c[5]; };
@@ -284,6 +293,7 @@ struct hcf_engine {
     const float* w = P(p + ".weight", {cout, cin, 3, 3});
     const float* b = P(p + ".bias", {cout});
     pack_conv(cv, w, b, nullptr, cin, cout, 3, srcs, act);
+    cv.wkey = p + ".weight"; cv.bkey = p + ".bias"; cv.lkey.clear(); cv.l_mult = 0.f;
   }
   // Basic.Conv2d with ActNorm (Basic.py:14-53) + ReLU
   void build_conv_an(Conv& cv, const std::string& p, int cin, int cout, int k, std::vector<int> srcs) {
@@ -295,6 +305,7 @@ struct hcf_engine {
       for (int i = 0; i < cout; ++i) sc[i] = expf(al[i]);
     pack_conv(cv, w, ab, al ? sc.data() : nullptr, cin, cout, k, srcs, ACT_RELU);
     cv.an_key = p + ".actnorm";
+    cv.wkey = p + ".weight"; cv.bkey = p + ".actnorm.bias"; cv.lkey = p + ".actnorm.logs"; cv.l_mult = 1.f;
   }
   // Basic.Conv2dZeros (Basic.py:57-72): (conv + bias) * exp(logs * 3)
   void build_conv_zeros(Conv& cv, const std::string& p, int cin, int cout, std::vector<int> srcs) {
@@ -305,6 +316,7 @@ struct hcf_engine {
     if (lg)
       for (int i = 0; i < cout; ++i) sc[i] = expf(lg[i] * 3.f);
     pack_conv(cv, w, b, lg ? sc.data() : nullptr, cin, cout, 3, srcs, ACT_NONE);
+    cv.wkey = p + ".weight"; cv.bkey = p + ".bias"; cv.lkey = p + ".logs"; cv.l_mult = 3.f;
   }
 
   static std::vector<int> srcs2(int a, int b) {
@@ -357,6 +369,7 @@ struct hcf_engine {
     s.hid = hid;
     s.fcn = (nn_module == HCF_NN_FCN);
     s.an_key = p + ".actnorm";
+    s.wkey = (perm == HCF_PERM_INVCONV) ? p + ".permute.weight" : std::string();
     if (s.cmax < 0) { fail(HCF_ERR_UNSUPPORTED, "flow step with more than 48 channels"); return; }
     const float* ab = P(p + ".actnorm.bias", {1, C, 1, 1});
     const float* al = P(p + ".actnorm.logs", {1, C, 1, 1});
@@ -418,6 +431,16 @@ struct hcf_engine {
         }
       s.mat_inv = upload(wi);
       s.mat_fwd = upload(wf);
+      {
+        std::vector<float> wt((size_t)M * M, 0.f), it((size_t)C * C, 0.f);
+        for (int r = 0; r < C; ++r)
+          for (int c = 0; c < C; ++c) {
+            wt[(size_t)c * M + r] = W[(size_t)r * C + c];
+            it[(size_t)c * C + r] = (float)inv[(size_t)r * C + c];
+          }
+        s.mat_fwdT = upload(wt);
+        s.winvT = upload(it);
+      }
       s.lad = lad;
       s.ld_const += lad;
     }
@@ -1025,9 +1048,12 @@ struct hcf_engine {
     }
   }
 
+#include "hcf_engine_train.inc"
+
   template <class F>
   int run_pass(F&& body, hipStream_t stream, uint32_t flags = 0) {
     pass_flags = flags;
+    tape_valid = false;          // the inference passes reuse the activation arena
     if (!finalized) return fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
@@ -1106,6 +1132,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->arena.base) hipFree(e->arena.base);
   if (e->ovf_flag) hipFree(e->ovf_flag);
   if (e->stats_dev) hipFree(e->stats_dev);
+  if (e->garena.base) hipFree(e->garena.base);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
@@ -1153,6 +1180,8 @@ int hcf_finalize(hcf_engine* e, int device) {
   }
   hipDeviceSynchronize();      // packed weights of a previous finalize may still be in use
   e->free_weights();
+  e->train_ready = false;
+  e->tape_valid = false;
   e->device = device;
   e->spec_mode = false;
   e->rc = HCF_OK;
@@ -1202,6 +1231,19 @@ int64_t hcf_fallback_count(const hcf_engine* e) { return e ? e->n_fallbacks : -1
 
 size_t hcf_workspace_bytes(const hcf_engine* e) { return e ? e->arena.cap : 0; }
 size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }
+
+int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr,
+                         float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream) {
+  if (!e || !hr || !lr || !noise || !out_lr || !out_nll || !out_logdet || B < 1 || H < 1 || W < 1) return HCF_ERR_ARG;
+  const int m = 1 << e->cfg.L;
+  if (H % m || W % m) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by the scale (squeeze2d assert, Basic.py:136)");
+  return e->run_train_forward(hr, lr, noise, out_lr, out_nll, out_logdet, B, H, W, (hipStream_t)stream);
+}
+
+int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream) {
+  if (!e || numel < 0) return HCF_ERR_ARG;
+  return e->run_backward(grad_nll, dparams, (size_t)numel, (hipStream_t)stream);
+}
 
 int hcf_actnorm_init_request(hcf_engine* e, const char* const* prefixes, int32_t n) {
   if (!e || n < 0 || (n > 0 && !prefixes)) return HCF_ERR_ARG;

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void step_head_fwd_kernel(const StepArgs a) {
   load_pixel<CMAX>(a.z, pix, a.C, z);
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) z[c] = (z[c] + a.an_bias[c]) * a.an_mul[c];   // (x + b) * exp(logs)
+  if (a.aux.p) store_pixel<CMAX>(a.aux, pix, a.C, z);                          // training tape: input of W
   if (a.mat) {
     float y[CMAX];
     matvec<CMAX>(const_table(a.mat), z, y);

@@ -1,0 +1,231 @@
+// Backward kernels of the NLL training step (the reference reaches them through autograd in
+// HCFlow_SR_model.optimize_parameters, HCFlow_SR_model.py:195-202). gfx950 only. Everything here is HBM-bound
+// elementwise / per-pixel work; the GEMM-shaped parts of the backward pass are the data-gradient convs (forward
+// kernels on transposed weight packs) and hcf_conv_wgrad.hip.
+#include "hcf_common.h"
+#include "hcf_step_math.h"
+
+namespace hcf {
+
+#define HCF_RET_T() return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP
+
+// ---- conv epilogue backward -----------------------------------------------------------------------------------
+// thread -> (pixel group, channel) so that consecutive threads touch consecutive floats of the NHWC windows;
+// per-channel sums: per-thread float partials -> LDS -> one atomicAdd per channel per block.
+__global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs a, long long npix, int ppb) {
+  __shared__ float sh[2][256];
+  const int n = a.gy.n;
+  const int groups = 256 / n;
+  const int pg = threadIdx.x / n, c = threadIdx.x - pg * n;
+  float s_pre = 0.f, s_zy = 0.f;
+  if (pg < groups) {
+    const float sc = a.scale ? a.scale[c] : 1.f;
+    const float k1 = a.has2 ? a.rs2 : 1.f;                 // gy -> gradient of (res1 + rs1 * act(..))
+    const float k2 = k1 * (a.has1 ? a.rs1 : 1.f);          // gy -> gradient of act(..)
+    const bool need_y = a.act != ACT_NONE || a.sum_zy != nullptr;
+    const long long p0 = (long long)blockIdx.x * ppb;
+    const long long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    for (long long p = p0 + pg; p < p1; p += groups) {
+      const float g = a.gy.p[(size_t)p * a.gy.cs + a.gy.c0 + c];
+      if (a.has2 && a.g2.p) a.g2.p[(size_t)p * a.g2.cs + a.g2.c0 + c] += g;
+      if (a.has1 && a.g1.p) a.g1.p[(size_t)p * a.g1.cs + a.g1.c0 + c] += g * k1;
+      const float y = need_y ? a.y.p[(size_t)p * a.y.cs + a.y.c0 + c] : 0.f;
+      float dz = g * k2;
+      if (a.act == ACT_RELU) dz = (y > 0.f) ? dz : 0.f;
+      else if (a.act == ACT_LRELU) dz = (y >= 0.f) ? dz : dz * 0.2f;
+      const float gp = dz * sc;
+      a.gpre.p[(size_t)p * a.gpre.cs + a.gpre.c0 + c] = gp;
+      s_pre += gp;
+      s_zy += dz * y;
+    }
+  }
+  if (a.sum_pre || a.sum_zy) {
+    sh[0][threadIdx.x] = s_pre;
+    sh[1][threadIdx.x] = s_zy;
+    __syncthreads();
+    if (threadIdx.x < n) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int g = 0; g < groups; ++g) { t0 += sh[0][g * n + threadIdx.x]; t1 += sh[1][g * n + threadIdx.x]; }
+      if (a.sum_pre) atomicAdd(a.sum_pre + threadIdx.x, t0);
+      if (a.sum_zy) atomicAdd(a.sum_zy + threadIdx.x, t1 * a.zy_mult);
+    }
+  }
+}
+
+int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st) {
+  if (a.gy.n < 1 || a.gy.n > 256 || a.gpre.n != a.gy.n) return HCF_ERR_ARG;
+  const long long npix = (long long)a.B * a.H * a.W;
+  const int ppb = 2048;
+  hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, st, a, npix, ppb);
+  HCF_RET_T();
+}
+
+// ---- coupling backward (AffineCouplings.py:44-63 forward; one thread per pixel) ---------------------------------
+__global__ __launch_bounds__(256) void step_couple_bwd_kernel(const StepBwdArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* gp = a.gzout.p + pix * a.gzout.cs + a.gzout.c0;
+  const float* zp = a.zout.p + pix * a.zout.cs + a.zout.c0;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  float* ob = a.gzb.p + pix * a.gzb.cs + a.gzb.c0;
+  float* oh = a.gh.p + pix * a.gh.cs + a.gh.c0;
+  if (a.mode == CPL_AFFINE) {
+    for (int c = 0; c < a.ns; ++c) ob[c] = gp[c];
+    for (int c = a.ns; c < a.C; ++c) {
+      const int j = c - a.ns;
+      const float scale = hp[2 * j + 1];
+      const float e = expf(logscale_of(scale));
+      const float g = gp[c];
+      ob[c] = g * e;                                             // z2' = (z2 + shift) e^ls
+      oh[2 * j] = g * e;                                         // d shift
+      const float dls = g * zp[c] + a.gobj;                      // d z2'/d ls = z2';  logdet += ls
+      oh[2 * j + 1] = dls * (0.636f / (1.f + 4.f * scale * scale));   // ls = 0.318 atan(2 scale)
+    }
+  } else {                                                       // z[:3] += h
+    for (int c = 0; c < a.C; ++c) ob[c] = gp[c];
+    for (int c = 0; c < 3; ++c) oh[c] = gp[c];
+  }
+}
+
+int launch_step_couple_bwd(const StepBwdArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1) return HCF_ERR_ARG;
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  hipLaunchKernelGGL(step_couple_bwd_kernel, grid, dim3(256), 0, st, a);
+  HCF_RET_T();
+}
+
+// ---- head backward: zb = W za, za = (zin + b) e^s  ->  gza = W^T gzb, gzin = gza e^s, sums for b and s -----------
+template <int CMAX>
+__global__ __launch_bounds__(256) void step_head_bwd_kernel(const StepBwdArgs a) {
+  __shared__ float sh[2][CMAX];
+  if (threadIdx.x < CMAX) { sh[0][threadIdx.x] = 0.f; sh[1][threadIdx.x] = 0.f; }
+  __syncthreads();
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < hw) {
+    const size_t pix = (size_t)blockIdx.y * hw + i;
+    float g[CMAX], gza[CMAX], za[CMAX];
+    load_pixel<CMAX>(a.gzb, pix, a.C, g);
+    load_pixel<CMAX>(a.za, pix, a.C, za);
+    if (a.matT) {
+      matvec<CMAX>(const_table(a.matT), g, gza);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) gza[c] = g[c];
+    }
+    const step_cptr mul = const_table(a.an_mul);
+    float gin[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      gin[c] = gza[c] * mul[c];
+      if (c < a.C) {
+        atomicAdd(&sh[0][c], gin[c]);              // d bias  = sum gza e^s
+        atomicAdd(&sh[1][c], gza[c] * za[c]);      // d logs  = sum gza * za
+      }
+    }
+    store_pixel<CMAX>(a.gzin, pix, a.C, gin);
+  }
+  __syncthreads();
+  if (threadIdx.x < a.C) {
+    atomicAdd(a.g_bias + threadIdx.x, sh[0][threadIdx.x]);
+    atomicAdd(a.g_logs + threadIdx.x, sh[1][threadIdx.x]);
+  }
+}
+
+int launch_step_head_bwd(const StepBwdArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1 || !a.g_bias || !a.g_logs) return HCF_ERR_ARG;
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  if (a.C <= 8) hipLaunchKernelGGL((step_head_bwd_kernel<8>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 12) hipLaunchKernelGGL((step_head_bwd_kernel<12>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 24) hipLaunchKernelGGL((step_head_bwd_kernel<24>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 48) hipLaunchKernelGGL((step_head_bwd_kernel<48>), grid, dim3(256), 0, st, a);
+  else return HCF_ERR_UNSUPPORTED;
+  HCF_RET_T();
+}
+
+// ---- Gaussian prior logp backward (Basic.py:78-93; SR: logs = s) --------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_logp_bwd_kernel(const PriorBwdArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* ap = a.a.p + pix * a.a.cs + a.a.c0;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  float* ga = a.ga.p + pix * a.ga.cs + a.ga.c0;
+  float* gh = a.gh.p + pix * a.gh.cs + a.gh.c0;
+  for (int c = 0; c < a.C; ++c) {
+    const float mean = hp[2 * c], logs = hp[2 * c + 1];
+    const float d = ap[c] - mean, iv = expf(-2.f * logs);
+    // logp = -1/2 (2 logs + d^2 e^{-2 logs} + ln 2pi)
+    ga[c] = -a.gobj * d * iv;
+    gh[2 * c] = a.gobj * d * iv;
+    gh[2 * c + 1] = a.gobj * (d * d * iv - 1.f);
+  }
+}
+
+int launch_gauss_logp_bwd(const PriorBwdArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  hipLaunchKernelGGL(gauss_logp_bwd_kernel, grid, dim3(256), 0, st, a);
+  HCF_RET_T();
+}
+
+// ---- Dirac term backward with the straight-through Quant (HCFlowNet_SR_arch.py:58-63, Basic.py:186-196) ----------
+__global__ __launch_bounds__(256) void quant_logp_bwd_kernel(View z, const float* lr, View gz, int hw, float gobj) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float e12 = expf(12.f);
+  for (int c = 0; c < 3; ++c) {
+    const float v = z.p[pix * z.cs + z.c0 + c];
+    const float q = rintf(fminf(fmaxf(v, 0.f), 1.f) * 255.f) / 255.f;
+    const float l = lr[((size_t)blockIdx.y * 3 + c) * hw + i];
+    // logp(x = q; mean = lr, logs = -6) = -1/2 (-12 + (q - lr)^2 e^12 + ln 2pi);  d/dq = -(q - lr) e^12
+    gz.p[pix * gz.cs + gz.c0 + c] += gobj * (l - q) * e12;
+  }
+}
+
+int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, int W, float gobj, hipStream_t st) {
+  const dim3 grid((unsigned)step_blocks_per_sample(H, W), (unsigned)B);
+  hipLaunchKernelGGL(quant_logp_bwd_kernel, grid, dim3(256), 0, st, z, lr_nchw, gz, H * W, gobj);
+  HCF_RET_T();
+}
+
+// ---- small helpers ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_view_kernel(View in, View out, int hw, float alpha) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = out.n;
+  if (e >= (long long)hw * n) return;
+  const int c = (int)(e % n);
+  const size_t pix = (size_t)blockIdx.y * hw + (size_t)(e / n);
+  out.p[pix * out.cs + out.c0 + c] += alpha * in.p[pix * in.cs + in.c0 + c];
+}
+int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st) {
+  if (in.n != out.n) return HCF_ERR_ARG;
+  const long long per = (long long)H * W * out.n;
+  hipLaunchKernelGGL(add_view_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, in, out, H * W, alpha);
+  HCF_RET_T();
+}
+
+__global__ __launch_bounds__(256) void add_const_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] += v;
+}
+int launch_add_const(float* p, size_t n, float v, hipStream_t st) {
+  if (n == 0) return HCF_OK;
+  hipLaunchKernelGGL(add_const_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  HCF_RET_T();
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* x, float* y, size_t n, float alpha) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] += alpha * x[i];
+}
+int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st) {
+  if (n == 0) return HCF_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, alpha);
+  HCF_RET_T();
+}
+
+}  // namespace hcf

@@ -135,6 +135,18 @@ int64_t hcf_fallback_count(const hcf_engine* e);
 size_t hcf_workspace_bytes(const hcf_engine* e);
 size_t hcf_weight_bytes(const hcf_engine* e);
 
+/* ---- NLL training step (reference: HCFlow_SR_model.optimize_parameters, HCFlow_SR_model.py:195-202:
+ *      `_, nll = netG(hr, lr, reverse=False); nll.backward()`) -------------------------------------------------
+ * hcf_train_forward_sr = hcf_forward_sr (same outputs; hr / lr / noise are required) that additionally keeps every
+ * intermediate tensor in HBM and records the backward pass. hcf_train_backward then writes
+ *   d(grad_nll * nll) / d(parameter)   for EVERY parameter, concatenated in hcf_param_info order (= state_dict
+ * order, each tensor flattened), into `dparams` (device buffer of `numel` = total parameter count floats); the
+ * caller slices it into its .grad tensors. One backward per forward; `lr` must stay alive in between. Exact fp32
+ * kernels; the weight-gradient atomics are the only run-to-run non-determinism. SR nets only. */
+int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr,
+                         float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
+int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
+
 /* ActNorm data-dependent initialisation (reference: _ActNorm.initialize_parameters, ActNorms.py:29-43, reached from
  * _ActNorm.forward when `not self.inited` in train() mode, :78-80). hcf_actnorm_init_request() arms the NEXT
  * hcf_forward_sr / hcf_forward_rescale call: each listed ActNorm (state_dict prefix, e.g.

@@ -51,3 +51,34 @@ def test_conv2d_backward(case, precision):
         assert _rel(d.cpu(), s.grad) <= 3e-6, (case, precision, _rel(d.cpu(), s.grad))
     assert _rel(dw, w64.grad) <= 3e-6, (case, _rel(dw, w64.grad))
     assert _rel(db, b64.grad) <= 1e-6
+
+
+GRADS = ["grad_sr4_tiny", "grad_sr8_tiny"]
+
+
+@pytest.mark.parametrize("name", GRADS)
+def test_nll_step_gradients_match_reference(name):
+    """One NLL step of HCFlow_SR_model.optimize_parameters (:195-199) through the drop-in module: nll and
+    d nll / d parameter for every tensor of the net against the reference-generated fixture."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import param_spec
+    from tests.util import load_golden, params_for, t
+    from tests.test_oracle_golden import check_grads_against_fixture
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").train()
+    lr_hat, nll = net(hr=t(g["hr"]).cuda(), lr=t(g["lr"]).cuda(), reverse=False, noise=t(g["fwd_noise"]).cuda())
+    assert abs(float(nll.detach()) - float(g["fwd_nll"])) <= 2e-4 * max(1.0, abs(float(g["fwd_nll"])) / 100)
+    assert float((lr_hat.cpu() - t(g["fwd_lr"])).abs().max()) <= 1e-4
+    (nll * 1.0).backward()
+    sd = dict(net.named_parameters())
+    grads = [np.zeros(tuple(sd[k].shape), np.float32) if sd[k].grad is None else sd[k].grad.cpu().numpy()
+             for k, _, _ in param_spec(cfg)]
+    assert all(np.isfinite(x).all() for x in grads)
+    check_grads_against_fixture(g, grads)
