@@ -82,3 +82,118 @@ def test_nll_step_gradients_match_reference(name):
              for k, _, _ in param_spec(cfg)]
     assert all(np.isfinite(x).all() for x in grads)
     check_grads_against_fixture(g, grads)
+
+
+def _fresh_sr(name, seed, inited=True):
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import preset
+    from tests.util import cached_params
+    cfg = preset(name)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(cached_params(name, seed), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = inited
+    return cfg, net.to("cuda:0")
+
+
+def test_training_steps_with_adam_reduce_nll_and_track_parameter_updates():
+    """A few optimiser steps as HCFlow_SR_model.optimize_parameters runs them (:184-205: nll.backward(), gradient
+    clipping, Adam): the loss falls on a fixed batch, every parameter gets a finite gradient, and the engine sees
+    the in-place parameter updates (the second forward differs from the first)."""
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(5)
+    hr = torch.rand(2, 3, 64, 64, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-4, betas=(0.9, 0.99))
+    losses = []
+    for it in range(4):
+        opt.zero_grad()
+        _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+        nll.backward()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.requires_grad)
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 100.0)
+        opt.step()
+        losses.append(float(nll.detach()))
+    assert losses[-1] < losses[0], losses
+    with torch.no_grad():
+        net.eval()
+        _, nll_eval = net(hr=hr, lr=lr, reverse=False, noise=noise)
+    assert float(nll_eval) < losses[0]
+
+
+def test_first_training_step_fits_actnorms_then_differentiates():
+    """train() mode, un-initialised ActNorms, autograd on: the ActNorms are fitted from this batch first (as the
+    reference does inside the same forward, ActNorms.py:78-80) and the returned nll / gradients are those of the
+    fitted net (checked against the oracle's autograd on the same inputs)."""
+    import numpy as np
+    from oracle import hcflow_oracle as O
+    from hcflow_amd.config import param_spec
+    from tests.util import cached_params
+    cfg, net = _fresh_sr("SR_4X_tiny", 11, inited=False)
+    an = [(k, m) for k, m in net.named_modules() if "ActNorm" in type(m).__name__]
+    with torch.no_grad():
+        for _, m in an:
+            m.bias.zero_()
+            m.logs.zero_()
+    net.train()
+    g = torch.Generator().manual_seed(6)
+    hr = torch.rand(2, 3, 48, 64, generator=g)
+    lr = torch.rand(2, 3, 12, 16, generator=g)
+    noise = torch.rand(hr.shape, generator=g)
+    _, nll = net(hr=hr.cuda(), lr=lr.cuda(), reverse=False, noise=noise.cuda())
+    nll.backward()
+    assert all(m.inited for _, m in an)
+    # oracle: fit on the same batch, then differentiate with the fitted values held fixed for the fit itself
+    p0 = {k: v.clone() for k, v in cached_params("SR_4X_tiny", 11).items()}
+    for k, _ in an:
+        p0[k + ".bias"] = torch.zeros_like(p0[k + ".bias"])
+        p0[k + ".logs"] = torch.zeros_like(p0[k + ".logs"])
+    ip = O.InitParams(p0, [k for k, _ in an])
+    with torch.no_grad():
+        O.sr_forward(hr, lr, ip, cfg, noise=noise)
+    q = {k: v.clone().requires_grad_(True) for k, v in ip.items()}
+    _, nll_o = O.sr_forward(hr, lr, q, cfg, noise=noise)
+    nll_o.backward()
+    assert abs(float(nll.detach()) - float(nll_o.detach())) <= 2e-4 * max(1.0, abs(float(nll_o.detach())) / 100)
+    sd = dict(net.named_parameters())
+    gmax = max(float(q[k].grad.norm()) for k, _, _ in param_spec(cfg) if q[k].grad is not None)
+    for k, _, _ in param_spec(cfg):
+        ref = q[k].grad
+        if ref is None:
+            continue
+        err = float((sd[k].grad.cpu() - ref).norm())
+        assert err <= 3e-4 * max(float(ref.norm()), 1e-6 * gmax), (k, err, float(ref.norm()))
+
+
+def test_ddp_wrapped_module_trains():
+    """nn.parallel.DistributedDataParallel(netG, device_ids=[dev]) as HCFlow_SR_model does (:33-36), world size 1
+    over RCCL: forward by keyword, backward, gradients identical to the unwrapped module."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(7)
+    hr = torch.rand(2, 3, 32, 32, generator=g).cuda()
+    lr = torch.rand(2, 3, 8, 8, generator=g).cuda()
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+    nll.backward()
+    want = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+    net.zero_grad()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ddp = DDP(net, device_ids=[0])
+        _, nll2 = ddp(hr=hr, lr=lr, reverse=False, noise=noise)
+        nll2.backward()
+        got = [p.grad for p in net.parameters() if p.requires_grad]
+        assert abs(float(nll2.detach()) - float(nll.detach())) <= 1e-6 * max(1.0, abs(float(nll.detach())))
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max()))
+    finally:
+        dist.destroy_process_group()
