@@ -26,7 +26,7 @@ SYMBOLS = [
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
-    "hcf_train_forward_sr", "hcf_train_backward",
+    "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
 ]
 
 
@@ -88,6 +88,8 @@ def load() -> C.CDLL:
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
     lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.hcf_bind_param_device.argtypes = [vp, C.c_char_p, fp]
+    lib.hcf_refresh_from_device.argtypes = [vp, vp]
     lib.hcf_train_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.hcf_train_backward.argtypes = [vp, f32, fp, i64, vp]
     lib.hcf_actnorm_init_request.argtypes = [vp, C.POINTER(C.c_char_p), i32]
@@ -198,6 +200,12 @@ class Engine:
         check(self.lib.hcf_get_param(self._h, key.encode(), C.c_void_p(out.data_ptr()), int(numel)), self._h,
               "hcf_get_param(%s)" % key)
         return out
+
+    def bind_param_device(self, key: str, data_ptr: int):
+        check(self.lib.hcf_bind_param_device(self._h, key.encode(), C.c_void_p(data_ptr)), self._h, "hcf_bind_param_device")
+
+    def refresh_from_device(self, stream):
+        check(self.lib.hcf_refresh_from_device(self._h, stream), self._h, "hcf_refresh_from_device")
 
     def finalize(self, device: int):
         check(self.lib.hcf_finalize(self._h, int(device)), self._h, "hcf_finalize")

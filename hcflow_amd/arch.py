@@ -310,10 +310,24 @@ class _EngineModule(nn.Module):
         stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if ent["stamp"] != stamp:
             eng = ent["engine"]
-            sd = self.state_dict()
-            for key, t in sd.items():
-                eng.set_param(key, t.detach().to("cpu", torch.float32).contiguous())
-            eng.finalize(idx)
+            named = list(self.named_parameters())
+            ptrs = tuple(p.data_ptr() for _, p in named)
+            on_dev = all(p.device.type == "cuda" and p.device.index == idx and p.dtype == torch.float32 and p.is_contiguous()
+                         for _, p in named)
+            if on_dev and ent.get("ptrs") == ptrs:
+                # same tensors, new contents (optimiser step): rewrite the packs on the device
+                with torch.cuda.device(idx):
+                    eng.refresh_from_device(self._stream(idx))
+            else:
+                sd = self.state_dict()
+                for key, t in sd.items():
+                    eng.set_param(key, t.detach().to("cpu", torch.float32).contiguous())
+                eng.finalize(idx)
+                ent["ptrs"] = None
+                if on_dev:
+                    for key, p in named:
+                        eng.bind_param_device(key, p.data_ptr())
+                    ent["ptrs"] = ptrs
             ent["stamp"] = stamp
         return ent["engine"], idx
 

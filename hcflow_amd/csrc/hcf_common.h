@@ -77,9 +77,26 @@ struct WgradArgs {
   int B, H, W;
   int taps;                // 9 (3x3, pad 1) or 1
   float* dw;               // [cout][cin_total][taps], accumulated (caller zero-initialises)
+  float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
+  size_t part_cap;         // capacity of `part` in floats
   int cin_total, tpb;      // set by the launcher
 };
+size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);
+
+// ---- device-side weight repack (hcf_repack.hip) -------------------------------------------------------------------
+struct RepackArgs {
+  const float* w;          // PyTorch-layout weight in device memory
+  int cin_w, taps;         // second dimension of w, taps (9 / 1)
+  int transposed, off;     // 1: data-gradient pack of w's input-channel block [off, off + cout)
+  int cout;                // output channels of the pack (forward: cout; transposed: block size)
+  int srcs[kMaxSrc], nsrc; // input windows of the packed conv (transposed: one window = the forward cout)
+  int nchunk, npad;
+  float* pk;               // exact pack or nullptr
+  _Float16* pk16;          // f16x3 pack or nullptr
+};
+int launch_repack_conv(const RepackArgs& a, hipStream_t st);
+int launch_repack_epilogue(int kind, const float* b, const float* l, int cout, float* bias, float* scale, hipStream_t st);
 
 // ---- flow-step glue --------------------------------------------------------------------------
 enum { CPL_AFFINE = 0, CPL_SHIFT3 = 1 };

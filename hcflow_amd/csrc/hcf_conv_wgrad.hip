@@ -10,8 +10,9 @@
 //            8 x 32 tile of G (32 channels) are staged in LDS as [pixel][32 ch] (conflict-free ds_read_b32: lane i
 //            reads channel i), wave w owns tile rows {2w, 2w+1} = 32 K-steps of two pixels, 9 MFMAs each (one per
 //            tap: the A operand is the same halo tile shifted by the tap);
-//   end    = the 4 waves' accumulators are summed through LDS and added to dW with fp32 atomics (several blocks
-//            share a dW tile; the order of those atomics is the only run-to-run non-determinism).
+//   end    = the 4 waves' accumulators are summed through LDS into the block's partial dW tile (scratch), and
+//            wgrad_reduce_kernel adds the partial tiles of the blocks that share a dW tile in a fixed order
+//            (deterministic; the first version used fp32 atomics and spent 10-25x the MFMA time in them).
 #include "hcf_common.h"
 
 namespace hcf {
@@ -44,8 +45,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const View sv = a.src[si];
   const int ic0 = blk * 32;                       // first channel of the block inside the window
   const int icn = min(32, sv.n - ic0);            // valid channels
-  int ic_base = 0;                                // channel offset of this window in the conv's input (cat order)
-  for (int j = 0; j < si; ++j) ic_base += a.src[j].n;
   const int oc0 = blockIdx.z * 32;
   const int ocn = min(32, a.g.n - oc0);
   const int up = sv.up, Hs = H >> up, Ws = W >> up;
@@ -119,8 +118,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
   }
 
-  // ---- cross-wave reduction through LDS, then atomics into dW[oc][ic][tap]
+  // ---- cross-wave reduction through LDS; the block's partial dW tile goes to scratch (coalesced), a second kernel
+  // sums the blocks that share a tile in a fixed order (deterministic; same-address atomics were 10-25x slower)
   float* red = xs;                                 // 4 waves x 1024 floats
+  float* part = a.part + ((size_t)((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (TAPS * 1024);
 #pragma unroll 1
   for (int t = 0; t < TAPS; ++t) {
     __syncthreads();
@@ -130,20 +131,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       red[wave * 1024 + m * 32 + li] = acc[t][r];
     }
     __syncthreads();
-    for (int e = tid; e < 1024; e += 256) {
-      const int m = e >> 5, n = e & 31;
-      if (m < icn && n < ocn) {
-        const float s = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
-        atomicAdd(a.dw + ((size_t)(oc0 + n) * a.cin_total + ic_base + ic0 + m) * TAPS + t, s);
-      }
-    }
+    for (int e = tid; e < 1024; e += 256) part[t * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
   }
+}
+
+// dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nx, int taps) {
+  const int icb = blockIdx.y, ocb = blockIdx.z;
+  const int e = blockIdx.x * 256 + threadIdx.x;          // (tap, m, n)
+  if (e >= taps * 1024) return;
+  const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
+  // locate the channel block
+  int blk = icb, si = 0, ic_base = 0;
+  for (; si < a.nsrc; ++si) {
+    const int nb = (a.src[si].n + 31) >> 5;
+    if (blk < nb) break;
+    blk -= nb;
+    ic_base += a.src[si].n;
+  }
+  const int ic = blk * 32 + m, oc = ocb * 32 + n;
+  if (ic >= a.src[si].n || oc >= a.g.n) return;
+  const size_t stride = (size_t)gridDim.y * gridDim.z * taps * 1024;
+  const float* p = a.part + ((size_t)icb * gridDim.z + ocb) * (taps * 1024) + e;
+  float s = 0.f;
+  for (int b = 0; b < nx; ++b) s += p[(size_t)b * stride];
+  a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += s;
 }
 
 }  // namespace wgrad
 
+size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_tpb) {
+  int nicb = 0;
+  for (int i = 0; i < a0.nsrc; ++i) nicb += (a0.src[i].n + 31) >> 5;
+  const int nocb = (a0.g.n + 31) >> 5;
+  const int tiles = a0.B * ((a0.W + 31) / 32) * ((a0.H + 7) / 8);
+  const int pairs = nicb * nocb;
+  int nblk_x = (1024 + pairs - 1) / pairs;          // ~4 blocks per CU in total
+  if (nblk_x > tiles) nblk_x = tiles;
+  if (nblk_x < 1) nblk_x = 1;
+  const int tpb = (tiles + nblk_x - 1) / nblk_x;
+  nblk_x = (tiles + tpb - 1) / tpb;
+  if (out_nblk_x) *out_nblk_x = nblk_x;
+  if (out_tpb) *out_tpb = tpb;
+  return (size_t)nblk_x * pairs * a0.taps * 1024;
+}
+
 int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
-  if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1) return HCF_ERR_ARG;
+  if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1 || !a0.part)
+    return HCF_ERR_ARG;
   WgradArgs a = a0;
   int nicb = 0, cin = 0;
   for (int i = 0; i < a.nsrc; ++i) {
@@ -152,17 +187,15 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
     cin += a.src[i].n;
   }
   a.cin_total = cin;
-  const int tiles = a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8);
-  const int pairs = nicb * ((a.g.n + 31) >> 5);
-  // enough blocks to fill 256 CUs x 2, but as few dW-tile sharers (atomics) as that allows
-  int nblk_x = (1024 + pairs - 1) / pairs;
-  if (nblk_x > tiles) nblk_x = tiles;
-  if (nblk_x < 1) nblk_x = 1;
-  a.tpb = (tiles + nblk_x - 1) / nblk_x;
-  nblk_x = (tiles + a.tpb - 1) / a.tpb;
-  const dim3 grid((unsigned)nblk_x, (unsigned)nicb, (unsigned)((a.g.n + 31) >> 5));
+  int nblk_x = 0;
+  const size_t need = conv_wgrad_scratch_floats(a, &nblk_x, &a.tpb);
+  if (need > a.part_cap) return HCF_ERR_NOMEM;
+  const int nocb = (a.g.n + 31) >> 5;
+  const dim3 grid((unsigned)nblk_x, (unsigned)nicb, (unsigned)nocb);
   if (a.taps == 9) hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<9>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  const dim3 rgrid((unsigned)((a.taps * 1024 + 255) / 256), (unsigned)nicb, (unsigned)nocb);
+  hipLaunchKernelGGL(wgrad::wgrad_reduce_kernel, rgrid, dim3(256), 0, st, a, nblk_x, a.taps);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 

@@ -190,7 +190,7 @@ struct hcf_engine {
   int* ovf_flag = nullptr;     // device: [0] = range flag, bytes 64..191 = zero page for the f16x3 kernel
   int64_t n_fallbacks = 0;
   // ActNorm data-dependent initialisation (ActNorms.py:29-43), armed for ONE forward pass by hcf_actnorm_init_request
-  std::set<std::string> an_pending;
+  std::set<std::string> an_pending, an_fitted;
   bool an_active = false;
   double* stats_dev = nullptr;   // 2 * 256 doubles
   float* unit_dev = nullptr;     // [0,256) zeros, [256,512) ones: identity epilogue of the statistics pass
@@ -658,6 +658,7 @@ struct hcf_engine {
       ib->second.data[c] = (float)(-mean);
       il->second.data[c] = (float)log(1.0 / (sqrt(var) + 1e-6));
     }
+    an_fitted.insert(key);
     return true;
   }
 
@@ -1133,6 +1134,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->ovf_flag) hipFree(e->ovf_flag);
   if (e->stats_dev) hipFree(e->stats_dev);
   if (e->garena.base) hipFree(e->garena.base);
+  if (e->wg_scratch) hipFree(e->wg_scratch);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
@@ -1182,6 +1184,7 @@ int hcf_finalize(hcf_engine* e, int device) {
   e->free_weights();
   e->train_ready = false;
   e->tape_valid = false;
+  e->host_stale = false;
   e->device = device;
   e->spec_mode = false;
   e->rc = HCF_OK;
@@ -1245,14 +1248,37 @@ int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t nu
   return e->run_backward(grad_nll, dparams, (size_t)numel, (hipStream_t)stream);
 }
 
+int hcf_bind_param_device(hcf_engine* e, const char* key, const float* dev_ptr) {
+  if (!e || !key) return HCF_ERR_ARG;
+  if (!e->params.count(key)) return e->fail(HCF_ERR_KEY, std::string("unknown parameter: ") + key);
+  e->dev_src[key] = dev_ptr;
+  return HCF_OK;
+}
+
+int hcf_refresh_from_device(hcf_engine* e, hcf_stream_t stream) {
+  if (!e) return HCF_ERR_ARG;
+  if (e->ensure_train_ready() != HCF_OK) return e->rc;     // the transposed packs exist before the first refresh
+  return e->refresh_from_device((hipStream_t)stream);
+}
+
 int hcf_actnorm_init_request(hcf_engine* e, const char* const* prefixes, int32_t n) {
   if (!e || n < 0 || (n > 0 && !prefixes)) return HCF_ERR_ARG;
   if (!e->finalized) return e->fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
   e->an_pending.clear();
+  e->an_fitted.clear();
   for (int i = 0; i < n; ++i) {
     if (!prefixes[i]) return HCF_ERR_ARG;
     const std::string k(prefixes[i]);
     if (!e->params.count(k + ".bias") || !e->params.count(k + ".logs")) return e->fail(HCF_ERR_KEY, "not an ActNorm: " + k);
+    if (e->host_stale) {        // the "is the bias still zero" rule (ActNorms.py:33-35) must see the current values
+      for (const char* suf : {".bias", ".logs"}) {
+        auto ds = e->dev_src.find(k + suf);
+        std::vector<float>& h = e->params[k + suf].data;
+        if (ds != e->dev_src.end() && ds->second &&
+            hipMemcpy(h.data(), ds->second, sizeof(float) * h.size(), hipMemcpyDeviceToHost) != hipSuccess)
+          return e->fail(HCF_ERR_HIP, "hcf_actnorm_init_request: D2H copy failed");
+      }
+    }
     e->an_pending.insert(k);
   }
   e->an_active = n > 0;
@@ -1264,6 +1290,15 @@ int hcf_get_param(hcf_engine* e, const char* key, float* out, int64_t numel) {
   auto it = e->params.find(key);
   if (it == e->params.end() || !it->second.set) return e->fail(HCF_ERR_KEY, std::string("unknown or unset parameter: ") + key);
   if ((int64_t)it->second.data.size() != numel) return e->fail(HCF_ERR_SHAPE, std::string("size mismatch for parameter: ") + key);
+  const std::string skey(key);
+  const size_t dot = skey.rfind('.');
+  const bool fitted = dot != std::string::npos && e->an_fitted.count(skey.substr(0, dot)) > 0;
+  if (e->host_stale && !fitted) {          // the authoritative copy is the caller's device tensor
+    auto ds = e->dev_src.find(key);
+    if (ds != e->dev_src.end() && ds->second &&
+        hipMemcpy(it->second.data.data(), ds->second, sizeof(float) * (size_t)numel, hipMemcpyDeviceToHost) != hipSuccess)
+      return e->fail(HCF_ERR_HIP, "hcf_get_param: D2H copy failed");
+  }
   memcpy(out, it->second.data.data(), sizeof(float) * (size_t)numel);
   return HCF_OK;
 }

@@ -244,6 +244,9 @@ int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const 
     wa.dw = t.dev(nw);
     if (!t.ok) return HCF_ERR_NOMEM;
     if (hipMemsetAsync(wa.dw, 0, nw * sizeof(float), st) != hipSuccess) return HCF_ERR_HIP;
+    wa.part_cap = conv_wgrad_scratch_floats(wa);
+    wa.part = t.dev(wa.part_cap);
+    if (!t.ok) return HCF_ERR_NOMEM;
     if (rc == HCF_OK) rc = launch_conv_wgrad(wa, st);
     if (rc == HCF_OK && hipMemcpyAsync(dw, wa.dw, nw * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) rc = HCF_ERR_HIP;
   }

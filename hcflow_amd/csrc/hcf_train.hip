@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
 int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st) {
   if (a.gy.n < 1 || a.gy.n > 256 || a.gpre.n != a.gy.n) return HCF_ERR_ARG;
   const long long npix = (long long)a.B * a.H * a.W;
-  const int ppb = 2048;
+  const int ppb = 96;          // >= 1000 blocks for a 16 x 80 x 80 tensor; one atomic per channel per block
   hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, st, a, npix, ppb);
   HCF_RET_T();
 }

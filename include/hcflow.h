@@ -147,6 +147,15 @@ int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const 
                          float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
 
+/* In-place parameter updates on the GPU (optimiser steps; reference: base_model / HCFlow_SR_model keep netG's
+ * parameters on the device and Adam updates them in place, HCFlow_SR_model.py:108-125,202). After hcf_finalize,
+ * hcf_bind_param_device tells the engine where each parameter lives in DEVICE memory (fp32, contiguous, same shape
+ * as hcf_param_info reports; the pointer must stay valid); hcf_refresh_from_device then rewrites every weight pack
+ * and table from those tensors with device kernels (host work only for the invertible 1x1 convs' fp64 inverse and
+ * log-determinant: one small D2H + H2D round trip) -- milliseconds instead of the host repack of hcf_finalize. */
+int hcf_bind_param_device(hcf_engine* e, const char* key, const float* dev_ptr);
+int hcf_refresh_from_device(hcf_engine* e, hcf_stream_t stream);
+
 /* ActNorm data-dependent initialisation (reference: _ActNorm.initialize_parameters, ActNorms.py:29-43, reached from
  * _ActNorm.forward when `not self.inited` in train() mode, :78-80). hcf_actnorm_init_request() arms the NEXT
  * hcf_forward_sr / hcf_forward_rescale call: each listed ActNorm (state_dict prefix, e.g.

@@ -197,3 +197,58 @@ def test_ddp_wrapped_module_trains():
             assert float((a - b).abs().max()) <= 1e-4 * max(1e-6, float(b.abs().max()))
     finally:
         dist.destroy_process_group()
+
+
+def test_device_refresh_equals_host_repack():
+    """After an in-place parameter update the engine refreshes its packs on the device (hcf_refresh_from_device);
+    forward, inverse (both precisions) and the next gradients must equal those of a freshly built engine fed the same
+    parameters through the host path (hcf_set_param + hcf_finalize)."""
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import eps_shapes
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(9)
+    hr = torch.rand(2, 3, 64, 96, generator=g).cuda()
+    lr = torch.rand(2, 3, 16, 24, generator=g).cuda()
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.7 for s in eps_shapes(cfg, 2, 16, 24)]
+    opt = torch.optim.SGD(net.parameters(), lr=1e-7)       # gradients reach 1e4 on these random weights
+    for _ in range(2):                                  # step 1: host path; step 2 sees a device refresh
+        opt.zero_grad()
+        _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+        nll.backward()
+        opt.step()
+    # third pass on the refreshed engine
+    opt.zero_grad()
+    _, nll_a = net(hr=hr, lr=lr, reverse=False, noise=noise)
+    nll_a.backward()
+    grads_a = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+    with torch.no_grad():
+        inv_a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.7, eps=eps, clamp=False)
+        net.set_precision("f16x3")
+        inv_a16 = net.reverse_flow_diracLR(lr, None, None, eps_std=0.7, eps=eps, clamp=False)
+        net.set_precision("exact")
+    assert net._engines[0]["ptrs"] is not None
+    # reference: a new module / engine with the same parameter values through the host path
+    ref = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    for m in ref.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    ref = ref.to("cuda:0").train()
+    _, nll_b = ref(hr=hr, lr=lr, reverse=False, noise=noise)
+    nll_b.backward()
+    grads_b = [p.grad for p in ref.parameters() if p.requires_grad]
+    assert float(nll_a.detach()) == float(nll_b.detach())
+    assert all(bool(torch.isfinite(x).all()) for x in grads_a)
+    gmax = max(float(b.abs().max()) for b in grads_b)
+    for a, b in zip(grads_a, grads_b):                  # 1-ulp expf differences in the scales + atomically summed bias grads
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-8 * gmax
+    with torch.no_grad():
+        inv_b = ref.reverse_flow_diracLR(lr, None, None, eps_std=0.7, eps=eps, clamp=False)
+        ref.set_precision("f16x3")
+        inv_b16 = ref.reverse_flow_diracLR(lr, None, None, eps_std=0.7, eps=eps, clamp=False)
+    # (the device refresh evaluates exp(logs) with the GPU's expf, the host path with libm: ~1 ulp in the epilogue scales)
+    scale = max(1.0, float(inv_b.abs().max()))
+    assert float((inv_a - inv_b).abs().max()) <= 2e-5 * scale
+    assert float((inv_a16 - inv_b16).abs().max()) <= 2e-5 * scale
