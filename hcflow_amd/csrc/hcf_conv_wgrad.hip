@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 32;
 
 template <int TAPS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   __shared__ __attribute__((aligned(16))) float xs[HP * 32];
@@ -57,49 +57,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // register staging: the NEXT tile's global loads are issued before this tile's MFMAs and land under them
+  constexpr int NX = (HP * 8 + 255) / 256, NG = (TH * TW * 8) / 256;
+  f32x4 rx[NX], rg[NG];
+#define HCF_WG_LOAD(TILE)                                                                                     \
+  {                                                                                                           \
+    const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, b_ = (TILE) / (tiles_x * tiles_y); \
+    const int x0_ = txb_ * TW, y0_ = tyb_ * TH;                                                               \
+    _Pragma("unroll") for (int s_ = 0; s_ < NX; ++s_) {                                                       \
+      const int q = tid + 256 * s_;                                                                           \
+      const int hp = min(q >> 3, HP - 1), c4 = (q & 7) * 4;                                                   \
+      const int hy = hp / HW, hx = hp - hy * HW;                                                              \
+      const int y = y0_ + hy - PAD, x = x0_ + hx - PAD;                                                       \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                         \
+      if (y >= 0 && y < H && x >= 0 && x < W && c4 < icn) {                                                   \
+        const float* p = sv.p + ((size_t)((size_t)b_ * Hs + (y >> up)) * Ws + (x >> up)) * sv.cs + sv.c0 + ic0 + c4; \
+        if (vecx && c4 + 4 <= icn) {                                                                          \
+          v = *reinterpret_cast<const f32x4*>(p);                                                             \
+        } else {                                                                                              \
+          v.x = p[0];                                                                                         \
+          if (c4 + 1 < icn) v.y = p[1];                                                                       \
+          if (c4 + 2 < icn) v.z = p[2];                                                                       \
+          if (c4 + 3 < icn) v.w = p[3];                                                                       \
+        }                                                                                                     \
+      }                                                                                                       \
+      rx[s_] = v;                                                                                             \
+    }                                                                                                         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NG; ++s_) {                                                       \
+      const int q = tid + 256 * s_;                                                                           \
+      const int px = q >> 3, c4 = (q & 7) * 4;                                                                \
+      const int y = y0_ + (px >> 5), x = x0_ + (px & 31);                                                     \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                         \
+      if (y < H && x < W && c4 < ocn) {                                                                       \
+        const float* p = a.g.p + ((size_t)((size_t)b_ * H + y) * W + x) * a.g.cs + a.g.c0 + oc0 + c4;        \
+        if (vecg && c4 + 4 <= ocn) {                                                                          \
+          v = *reinterpret_cast<const f32x4*>(p);                                                             \
+        } else {                                                                                              \
+          v.x = p[0];                                                                                         \
+          if (c4 + 1 < ocn) v.y = p[1];                                                                       \
+          if (c4 + 2 < ocn) v.z = p[2];                                                                       \
+          if (c4 + 3 < ocn) v.w = p[3];                                                                       \
+        }                                                                                                     \
+      }                                                                                                       \
+      rg[s_] = v;                                                                                             \
+    }                                                                                                         \
+  }
   const int t0 = blockIdx.x * a.tpb, t1 = min(ntiles, t0 + a.tpb);
+  if (t0 < t1) HCF_WG_LOAD(t0)
   for (int tile = t0; tile < t1; ++tile) {
-    const int txb = tile % tiles_x, tyb = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
-    const int x0 = txb * TW, y0 = tyb * TH;
     __syncthreads();                              // the previous tile's fragments have been read
-    // ---- stage X halo: HP pixels x 8 float4
-    for (int q = tid; q < HP * 8; q += 256) {
-      const int hp = q >> 3, c4 = (q & 7) * 4;
-      const int hy = hp / HW, hx = hp - hy * HW;
-      const int y = y0 + hy - PAD, x = x0 + hx - PAD;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y >= 0 && y < H && x >= 0 && x < W && c4 < icn) {
-        const float* p = sv.p + ((size_t)((size_t)b * Hs + (y >> up)) * Ws + (x >> up)) * sv.cs + sv.c0 + ic0 + c4;
-        if (vecx && c4 + 4 <= icn) {
-          v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-          v.x = p[0];
-          if (c4 + 1 < icn) v.y = p[1];
-          if (c4 + 2 < icn) v.z = p[2];
-          if (c4 + 3 < icn) v.w = p[3];
-        }
-      }
-      *reinterpret_cast<f32x4*>(xs + hp * 32 + c4) = v;
+#pragma unroll
+    for (int s_ = 0; s_ < NX; ++s_) {
+      const int q = tid + 256 * s_;
+      if (q < HP * 8) *reinterpret_cast<f32x4*>(xs + (q >> 3) * 32 + (q & 7) * 4) = rx[s_];
     }
-    // ---- stage G: 256 pixels x 8 float4
-    for (int q = tid; q < TH * TW * 8; q += 256) {
-      const int px = q >> 3, c4 = (q & 7) * 4;
-      const int y = y0 + (px >> 5), x = x0 + (px & 31);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y < H && x < W && c4 < ocn) {
-        const float* p = a.g.p + ((size_t)((size_t)b * H + y) * W + x) * a.g.cs + a.g.c0 + oc0 + c4;
-        if (vecg && c4 + 4 <= ocn) {
-          v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-          v.x = p[0];
-          if (c4 + 1 < ocn) v.y = p[1];
-          if (c4 + 2 < ocn) v.z = p[2];
-          if (c4 + 3 < ocn) v.w = p[3];
-        }
-      }
-      *reinterpret_cast<f32x4*>(gs + px * 32 + c4) = v;
+#pragma unroll
+    for (int s_ = 0; s_ < NG; ++s_) {
+      const int q = tid + 256 * s_;
+      *reinterpret_cast<f32x4*>(gs + (q >> 3) * 32 + (q & 7) * 4) = rg[s_];
     }
     __syncthreads();
+    if (tile + 1 < t1) HCF_WG_LOAD(tile + 1)
     // ---- 2 rows x 16 pixel pairs per wave
 #pragma unroll 1
     for (int rr = 0; rr < 2; ++rr) {
@@ -117,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       }
     }
   }
+#undef HCF_WG_LOAD
 
   // ---- cross-wave reduction through LDS; the block's partial dW tile goes to scratch (coalesced), a second kernel
   // sums the blocks that share a tile in a fixed order (deterministic; same-address atomics were 10-25x slower)
@@ -153,8 +172,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
   if (ic >= a.src[si].n || oc >= a.g.n) return;
   const size_t stride = (size_t)gridDim.y * gridDim.z * taps * 1024;
   const float* p = a.part + ((size_t)icb * gridDim.z + ocb) * (taps * 1024) + e;
-  float s = 0.f;
-  for (int b = 0; b < nx; ++b) s += p[(size_t)b * stride];
+  // fixed summation order (8 interleaved partial sums, then their sum): deterministic, and 8 loads in flight
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 8 <= nx; b += 8)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] += p[(size_t)(b + j) * stride];
+  for (; b < nx; ++b) s8[b & 7] += p[(size_t)b * stride];
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += s;
 }
 
