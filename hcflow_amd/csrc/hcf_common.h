@@ -58,6 +58,7 @@ struct ConvArgs {
   // f16x3 kernel, optional fused inverse flow-step tail (tC > 0): z <- actnorm^-1(W^-1 coupling^-1(z, h = this conv))
   View tz; View tzo; const float* tmat; const float* tbias; const float* tmul; int tC, tns, tmode;
   const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
+  const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
 };
 
@@ -141,6 +142,7 @@ struct EpiBwdArgs {
   float* sum_pre;          // nullable
   float* sum_zy;           // nullable
   float zy_mult;
+  float* absmax;           // nullable: max |gpre| as float bits (atomicMax on the int view; zero-initialised)
 };
 int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st);
 

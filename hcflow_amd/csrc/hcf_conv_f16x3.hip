@@ -100,9 +100,13 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // invertible 1x1 conv and ActNorm^-1 to z in place. TAILC = register-array bucket for z (8 / 12 / 24 / 48).
 // TH = tile height (8: 4 waves / 256 threads; 16: 8 waves / 512 threads). The taller tile halves the weight
 // staging per pixel, trims the halo overhead (1.33x -> 1.2x) and halves the staging registers per thread.
-template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8>
+// SCALED (training, data-gradient convs): the input tensor is multiplied by a power of two derived from its max |x|
+// (a.in_max, device) before the split and the accumulators are scaled back in the epilogue: gradients of 1e-8 would
+// otherwise fall below the f16 split's absolute floor (a_lo is unscaled).
+template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false>
 __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
+  static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
   static_assert(TH == 8 || (!FUSE2 && TAILC == 0), "fused epilogues are sized for the 8-row tile");
   constexpr int NTHR = 32 * TH;
   // Interleaving the next chunk's split into the last taps is worth ~10 % on the plain kernels. The fused-tail
@@ -177,6 +181,16 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
   const gf4ptr wq = (gf4ptr)uniform_ptr(a.wpack) + tid;   // this thread's float4 lane of the weight stream
   const gfptr zpage = uniform_ptr(a.zeros);
+  float in_s = 1.f, out_s = 1.f;                 // SCALED: x * in_s lands in [2^9, 2^10] at the tensor's max |x|
+  if (SCALED) {
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.in_max)));
+    if (mx > 0.f && mx < 3.0e38f) {
+      int ex = 0;
+      (void)frexpf(mx, &ex);                     // mx = m * 2^ex, m in [0.5, 1)
+      in_s = ldexpf(1.f, 10 - ex);
+      out_s = ldexpf(1.f, ex - 10);
+    }
+  }
 
   int stg_valid = 0;       // valid channels (0..4+) of this thread's 4-channel unit in the staged chunk
   f32x4 stg[NSLOT];        // next chunk's activations: fp32 after the load, (hi, lo) f16 pairs after the split
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #define HCF_SPLIT_SLOT(S)                                                                         \
   {                                                                                               \
     f32x4 v = stg[S];                                                                             \
+    if (SCALED) { v.x *= in_s; v.y *= in_s; v.z *= in_s; v.w *= in_s; }                            \
     if (HCF_DBG_NOZPAGE && !((okmask >> (S)) & 1u)) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; } \
     if (stg_valid < 4) {                                                                          \
       v.x = (stg_valid > 0) ? v.x : 0.f;                                                          \
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int cout = a.out.n;
   const int oc = wn * 32 + li;
   const bool ocok = oc < cout;
-  constexpr float UNSPLIT = 1.0f / SPLIT;
+  const float UNSPLIT = SCALED ? out_s / SPLIT : 1.0f / SPLIT;
   // Range check: an input with |a| >= 65504 becomes inf in the hi plane and turns every accumulator it
   // touches into inf / NaN (inf * 0 = NaN), so testing the RAW accumulators is sufficient, and 12x
   // cheaper than testing every staged element of every chunk.
@@ -521,7 +536,7 @@ int g_f16x3_tall = 0;   // 16-row tile variants measured no better than the 8-ro
 
 template <int NTB>
 static int launch_t(const ConvArgs& a, hipStream_t st) {
-  const bool plain = !(a.tC > 0) && !a.w2;
+  const bool plain = !(a.tC > 0) && !a.w2 && !a.in_max;
   const bool tall = plain && (((g_f16x3_tall ^ g_f16x3_ablation) >> (NTB - 1)) & 1) && a.H >= 16;   // --ablate 1/2/3 turns it off
   const int THr = tall ? 16 : 8;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + THr - 1) / THr;
@@ -563,6 +578,10 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
   else if (tall)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
+  else if (a.in_max && vec && !b.any_up)
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  else if (a.in_max)
+    return HCF_ERR_UNSUPPORTED;
   else if (vec && !b.any_up)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else if (vec)

@@ -189,6 +189,7 @@ struct hcf_engine {
   bool use_f16 = false;        // precision of the pass being enqueued
   int* ovf_flag = nullptr;     // device: [0] = range flag, bytes 64..191 = zero page for the f16x3 kernel
   int64_t n_fallbacks = 0;
+  bool taping = false;         // a training forward is being recorded: no fused epilogues
   // ActNorm data-dependent initialisation (ActNorms.py:29-43), armed for ONE forward pass by hcf_actnorm_init_request
   std::set<std::string> an_pending, an_fitted;
   bool an_active = false;
@@ -550,6 +551,7 @@ struct hcf_engine {
   // f16x3 mode can run FCN conv1 (3x3 -> 64) and conv2 (1x1 64 -> 64) as ONE launch
   bool can_fuse_fcn(const Conv& c1, const Conv& c2) const {
     if (getenv("HCF_NO_FUSE_FCN")) return false;      // debugging aid
+    if (taping) return false;                         // the backward pass needs the intermediate tensor
     return use_f16 && c1.wpack16 && c2.wpack16 && c1.taps == 9 && c2.taps == 1 && c1.cout == 64 && c2.cout == 64 &&
            c2.nsrc == 1 && c2.src_n[0] == 64;
   }
@@ -720,6 +722,7 @@ struct hcf_engine {
   // f16x3 mode: the last conv of an FCN coupling net can finish the inverse flow step in its epilogue
   bool can_fuse_tail(const Step& s) const {
     if (getenv("HCF_NO_FUSE_TAIL")) return false;     // debugging aid
+    if (taping) return false;
     const Conv& c = s.c[2];
     const int lim = getenv("HCF_TAIL_CMAX") ? atoi(getenv("HCF_TAIL_CMAX")) : 24;
     return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= lim;   // the 48-channel variant spills

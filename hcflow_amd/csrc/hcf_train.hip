@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
   const int n = a.gy.n;
   const int groups = 256 / n;
   const int pg = threadIdx.x / n, c = threadIdx.x - pg * n;
-  float s_pre = 0.f, s_zy = 0.f;
+  float s_pre = 0.f, s_zy = 0.f, mx = 0.f;
   if (pg < groups) {
     const float sc = a.scale ? a.scale[c] : 1.f;
     const float k1 = a.has2 ? a.rs2 : 1.f;                 // gy -> gradient of (res1 + rs1 * act(..))
@@ -37,7 +37,16 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
       a.gpre.p[(size_t)p * a.gpre.cs + a.gpre.c0 + c] = gp;
       s_pre += gp;
       s_zy += dz * y;
+      mx = fmaxf(mx, fabsf(gp));
     }
+  }
+  if (a.absmax) {                                  // non-negative floats order like their bit patterns
+    __shared__ int shm;
+    if (threadIdx.x == 0) shm = 0;
+    __syncthreads();
+    if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
+    __syncthreads();
+    if (threadIdx.x == 0 && shm) atomicMax(reinterpret_cast<int*>(a.absmax), shm);
   }
   if (a.sum_pre || a.sum_zy) {
     sh[0][threadIdx.x] = s_pre;

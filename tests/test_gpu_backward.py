@@ -56,8 +56,9 @@ def test_conv2d_backward(case, precision):
 GRADS = ["grad_sr4_tiny", "grad_sr8_tiny"]
 
 
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
 @pytest.mark.parametrize("name", GRADS)
-def test_nll_step_gradients_match_reference(name):
+def test_nll_step_gradients_match_reference(name, precision):
     """One NLL step of HCFlow_SR_model.optimize_parameters (:195-199) through the drop-in module: nll and
     d nll / d parameter for every tensor of the net against the reference-generated fixture."""
     import numpy as np
@@ -72,7 +73,7 @@ def test_nll_step_gradients_match_reference(name):
     for m in net.modules():
         if "ActNorm" in type(m).__name__:
             m.inited = True
-    net = net.to("cuda:0").train()
+    net = net.to("cuda:0").train().set_precision(precision)     # f16x3: forward + data-gradient 3x3 convs on the split kernels
     lr_hat, nll = net(hr=t(g["hr"]).cuda(), lr=t(g["lr"]).cuda(), reverse=False, noise=t(g["fwd_noise"]).cuda())
     assert abs(float(nll.detach()) - float(g["fwd_nll"])) <= 2e-4 * max(1.0, abs(float(g["fwd_nll"])) / 100)
     assert float((lr_hat.cpu() - t(g["fwd_lr"])).abs().max()) <= 1e-4
@@ -81,6 +82,7 @@ def test_nll_step_gradients_match_reference(name):
     grads = [np.zeros(tuple(sd[k].shape), np.float32) if sd[k].grad is None else sd[k].grad.cpu().numpy()
              for k, _, _ in param_spec(cfg)]
     assert all(np.isfinite(x).all() for x in grads)
+    assert net.engine().fallback_count() == 0
     check_grads_against_fixture(g, grads)
 
 

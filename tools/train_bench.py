@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--hr", type=int, default=160)
     ap.add_argument("--preset", default="SR_DF2K_4X")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "exact"])
     args = ap.parse_args()
     cfg = preset(args.preset)
     with contextlib.redirect_stdout(sys.stderr):
@@ -28,7 +29,7 @@ def main():
     for m in net.modules():
         if "ActNorm" in type(m).__name__:
             m.inited = True
-    net = net.cuda().train()
+    net = net.cuda().train().set_precision(args.precision)
     g = torch.Generator().manual_seed(0)
     B, H = args.batch, args.hr
     hr = torch.rand(B, 3, H, H, generator=g).cuda()
