@@ -81,6 +81,7 @@ struct WgradArgs {
   float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
   size_t part_cap;         // capacity of `part` in floats
   int cin_total, tpb;      // set by the launcher
+  int dbg;                 // timing ablations (HCF_WG_DBG): 1 no MFMAs, 2 no epilogue, 4 no global loads
 };
 size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);

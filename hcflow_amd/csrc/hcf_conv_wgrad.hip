@@ -5,15 +5,17 @@
 // X is the forward input (the same <= 3 NHWC source windows, optionally read through a nearest upsample), G the
 // gradient w.r.t. the conv's pre-activation output. Per tap this is a GEMM with M = input channels, N = output
 // channels, K = pixels, run on v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation):
-//   block  = 4 waves, one (32 input channels) x (32 output channels) tile of dW, all taps;
+//   block  = 4 waves, one (32 input channels) x (32 output channels) tile of dW, all taps; each wave owns a 16 x 16
+//            quadrant (16x16x4 MFMAs: 4 accumulator registers per tap -- a 32x32 tile per wave needs 144 and spilled);
 //   K loop = the block walks `tpb` pixel tiles of 8 x 32; per tile the 10 x 34 halo of X (32 channels) and the
-//            8 x 32 tile of G (32 channels) are staged in LDS as [pixel][32 ch] (conflict-free ds_read_b32: lane i
-//            reads channel i), wave w owns tile rows {2w, 2w+1} = 32 K-steps of two pixels, 9 MFMAs each (one per
-//            tap: the A operand is the same halo tile shifted by the tap);
-//   end    = the 4 waves' accumulators are summed through LDS into the block's partial dW tile (scratch), and
+//            8 x 32 tile of G (32 channels) are staged in LDS as [pixel][32 ch] (conflict-free ds_read_b32), every
+//            wave runs 64 K-steps of four pixels, 9 MFMAs each (one per tap: the A operand is the same halo tile
+//            shifted by the tap); the next tile's global loads are in flight meanwhile (register staging);
+//   end    = each wave stores its quadrant of the block's partial dW tile (scratch), and
 //            wgrad_reduce_kernel adds the partial tiles of the blocks that share a dW tile in a fixed order
 //            (deterministic; the first version used fp32 atomics and spent 10-25x the MFMA time in them).
 #include "hcf_common.h"
+#include <cstdlib>
 
 namespace hcf {
 namespace wgrad {
@@ -23,14 +25,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 32;
 
-template <int TAPS>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
+template <int TAPS, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int PAD = (TAPS == 9) ? 1 : 0;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   __shared__ __attribute__((aligned(16))) float xs[HP * 32];
   __shared__ __attribute__((aligned(16))) float gs[TH * TW * 32];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = a.H, W = a.W;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = a.B * tiles_x * tiles_y;
@@ -48,110 +50,125 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradArgs a) {
   const int oc0 = blockIdx.z * 32;
   const int ocn = min(32, a.g.n - oc0);
   const int up = sv.up, Hs = H >> up, Ws = W >> up;
-  const bool vecx = (((sv.cs | (sv.c0 + ic0)) & 3) == 0) && ((reinterpret_cast<uintptr_t>(sv.p) & 15) == 0);
-  const bool vecg = (((a.g.cs | (a.g.c0 + oc0)) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.g.p) & 15) == 0);
 
-  f32x16 acc[TAPS];
+  // wave (qi, qj) owns the 16 x 16 quadrant [16 qi, +16) x [16 qj, +16) of the 32 x 32 dW tile for all taps
+  // (v_mfma_f32_16x16x4_f32: 4 accumulator registers per tap) and walks all 256 pixels of every tile
+  const int qi = wave >> 1, qj = wave & 1, l16 = lane & 15, kk = lane >> 4;
+  f32x4 acc[TAPS];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // register staging: the NEXT tile's global loads are issued before this tile's MFMAs and land under them
+  // register staging: the NEXT tile's global loads are issued before this tile's MFMAs and land under them.
+  // Branch-free: coordinates and channel offsets are clamped into the tensor so every load is unconditional
+  // (per-slot branches made the compiler wait for each load in turn: 19 serial memory latencies per tile);
+  // out-of-image pixels and channel tails are zeroed by masks when the registers go to LDS.
   constexpr int NX = (HP * 8 + 255) / 256, NG = (TH * TW * 8) / 256;
   f32x4 rx[NX], rg[NG];
+  unsigned mskx = 0, mskg = 0;                       // bit s: the pixel of slot s is inside the image
+  const int c4t = (tid & 7) * 4;                     // this thread's 4-channel unit (same in every slot)
+  const int vx = max(0, min(4, icn - c4t)), vg = max(0, min(4, ocn - c4t));      // valid channels of the unit
+  const int c4x = min(c4t, max(0, (icn - 1) & ~3)), c4g = min(c4t, max(0, (ocn - 1) & ~3));
+  const float* const xbase = sv.p + sv.c0 + ic0;
+  const float* const gbase = a.g.p + a.g.c0 + oc0;
 #define HCF_WG_LOAD(TILE)                                                                                     \
   {                                                                                                           \
     const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, b_ = (TILE) / (tiles_x * tiles_y); \
     const int x0_ = txb_ * TW, y0_ = tyb_ * TH;                                                               \
+    mskx = 0;                                                                                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < NX; ++s_) {                                                       \
-      const int q = tid + 256 * s_;                                                                           \
-      const int hp = min(q >> 3, HP - 1), c4 = (q & 7) * 4;                                                   \
+      const int hp = min((tid + 256 * s_) >> 3, HP - 1);                                                      \
       const int hy = hp / HW, hx = hp - hy * HW;                                                              \
       const int y = y0_ + hy - PAD, x = x0_ + hx - PAD;                                                       \
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                         \
-      if (y >= 0 && y < H && x >= 0 && x < W && c4 < icn) {                                                   \
-        const float* p = sv.p + ((size_t)((size_t)b_ * Hs + (y >> up)) * Ws + (x >> up)) * sv.cs + sv.c0 + ic0 + c4; \
-        if (vecx && c4 + 4 <= icn) {                                                                          \
-          v = *reinterpret_cast<const f32x4*>(p);                                                             \
-        } else {                                                                                              \
-          v.x = p[0];                                                                                         \
-          if (c4 + 1 < icn) v.y = p[1];                                                                       \
-          if (c4 + 2 < icn) v.z = p[2];                                                                       \
-          if (c4 + 3 < icn) v.w = p[3];                                                                       \
-        }                                                                                                     \
+      mskx |= (y >= 0 && y < H && x >= 0 && x < W) ? (1u << s_) : 0u;                                         \
+      const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                           \
+      const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                            \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4x);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, icn - 1)]; v.y = p[min(c4t + 1, icn - 1)];                                           \
+        v.z = p[min(c4t + 2, icn - 1)]; v.w = p[min(c4t + 3, icn - 1)];                                       \
       }                                                                                                       \
       rx[s_] = v;                                                                                             \
     }                                                                                                         \
+  }
+#define HCF_WG_LOAD_G(TILE)                                                                                   \
+  {                                                                                                           \
+    const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, b_ = (TILE) / (tiles_x * tiles_y); \
+    const int x0_ = txb_ * TW, y0_ = tyb_ * TH;                                                               \
+    mskg = 0;                                                                                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < NG; ++s_) {                                                       \
-      const int q = tid + 256 * s_;                                                                           \
-      const int px = q >> 3, c4 = (q & 7) * 4;                                                                \
+      const int px = (tid + 256 * s_) >> 3;                                                                   \
       const int y = y0_ + (px >> 5), x = x0_ + (px & 31);                                                     \
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                         \
-      if (y < H && x < W && c4 < ocn) {                                                                       \
-        const float* p = a.g.p + ((size_t)((size_t)b_ * H + y) * W + x) * a.g.cs + a.g.c0 + oc0 + c4;        \
-        if (vecg && c4 + 4 <= ocn) {                                                                          \
-          v = *reinterpret_cast<const f32x4*>(p);                                                             \
-        } else {                                                                                              \
-          v.x = p[0];                                                                                         \
-          if (c4 + 1 < ocn) v.y = p[1];                                                                       \
-          if (c4 + 2 < ocn) v.z = p[2];                                                                       \
-          if (c4 + 3 < ocn) v.w = p[3];                                                                       \
-        }                                                                                                     \
+      mskg |= (y < H && x < W) ? (1u << s_) : 0u;                                                             \
+      const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;       \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4g);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, ocn - 1)]; v.y = p[min(c4t + 1, ocn - 1)];                                           \
+        v.z = p[min(c4t + 2, ocn - 1)]; v.w = p[min(c4t + 3, ocn - 1)];                                       \
       }                                                                                                       \
       rg[s_] = v;                                                                                             \
     }                                                                                                         \
   }
   const int t0 = blockIdx.x * a.tpb, t1 = min(ntiles, t0 + a.tpb);
-  if (t0 < t1) HCF_WG_LOAD(t0)
+  const int dbg = a.dbg;
+  if (t0 < t1 && !(dbg & 4)) HCF_WG_LOAD(t0)
+  if (t0 < t1 && !(dbg & 4)) HCF_WG_LOAD_G(t0)
   for (int tile = t0; tile < t1; ++tile) {
     __syncthreads();                              // the previous tile's fragments have been read
 #pragma unroll
     for (int s_ = 0; s_ < NX; ++s_) {
       const int q = tid + 256 * s_;
-      if (q < HP * 8) *reinterpret_cast<f32x4*>(xs + (q >> 3) * 32 + (q & 7) * 4) = rx[s_];
+      f32x4 v = rx[s_];
+      const bool ok = (mskx >> s_) & 1u;
+      v.x = (ok && vx > 0) ? v.x : 0.f; v.y = (ok && vx > 1) ? v.y : 0.f;
+      v.z = (ok && vx > 2) ? v.z : 0.f; v.w = (ok && vx > 3) ? v.w : 0.f;
+      if (q < HP * 8) *reinterpret_cast<f32x4*>(xs + (q >> 3) * 32 + c4t) = v;
     }
 #pragma unroll
     for (int s_ = 0; s_ < NG; ++s_) {
       const int q = tid + 256 * s_;
-      *reinterpret_cast<f32x4*>(gs + (q >> 3) * 32 + (q & 7) * 4) = rg[s_];
+      f32x4 v = rg[s_];
+      const bool ok = (mskg >> s_) & 1u;
+      v.x = (ok && vg > 0) ? v.x : 0.f; v.y = (ok && vg > 1) ? v.y : 0.f;
+      v.z = (ok && vg > 2) ? v.z : 0.f; v.w = (ok && vg > 3) ? v.w : 0.f;
+      *reinterpret_cast<f32x4*>(gs + (q >> 3) * 32 + c4t) = v;
     }
     __syncthreads();
-    if (tile + 1 < t1) HCF_WG_LOAD(tile + 1)
-    // ---- 2 rows x 16 pixel pairs per wave
+    if (tile + 1 < t1 && !(dbg & 4)) { HCF_WG_LOAD(tile + 1) HCF_WG_LOAD_G(tile + 1) }
+    if (dbg & 1) continue;
+    // ---- K loop: 8 rows x 8 groups of 4 pixels; A[m = l16][k = kk] = X[pixel + tap][16 qi + l16], B = G[pixel][16 qj + l16]
 #pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = 2 * wave + rr;
+    for (int row = 0; row < TH; ++row) {
 #pragma unroll 4
-      for (int pp = 0; pp < 16; ++pp) {
-        const int xx = 2 * pp + half;
-        const float bg = gs[(row * TW + xx) * 32 + li];                  // B[k = half][n = li]
+      for (int g = 0; g < TW / 4; ++g) {
+        const int xx = 4 * g + kk;
+        const float bg = gs[(row * TW + xx) * 32 + qj * 16 + l16];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
           const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
-          const float ax = xs[((row + dy) * HW + xx + dx) * 32 + li];    // A[m = li][k = half]
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bg, acc[t], 0, 0, 0);
+          const float ax = xs[((row + dy) * HW + xx + dx) * 32 + qi * 16 + l16];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bg, acc[t], 0, 0, 0);
         }
       }
     }
   }
 #undef HCF_WG_LOAD
+#undef HCF_WG_LOAD_G
 
   // ---- cross-wave reduction through LDS; the block's partial dW tile goes to scratch (coalesced), a second kernel
   // sums the blocks that share a tile in a fixed order (deterministic; same-address atomics were 10-25x slower)
-  float* red = xs;                                 // 4 waves x 1024 floats
+  if (dbg & 2) return;
+  // ---- the block's partial dW tile goes to scratch ([tap][m][n], 64-byte runs); a second kernel sums the blocks that
+  // share a tile in a fixed order (deterministic; same-address atomics were 10-25x slower)
   float* part = a.part + ((size_t)((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (TAPS * 1024);
-#pragma unroll 1
-  for (int t = 0; t < TAPS; ++t) {
-    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;                  // input channel within the block
-      red[wave * 1024 + m * 32 + li] = acc[t][r];
-    }
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) part[t * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
-  }
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                       // D[row = 4 kk + r][col = l16]
+      part[t * 1024 + (qi * 16 + 4 * kk + r) * 32 + qj * 16 + l16] = acc[t][r];
 }
 
 // dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
@@ -191,7 +208,7 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   const int nocb = (a0.g.n + 31) >> 5;
   const int tiles = a0.B * ((a0.W + 31) / 32) * ((a0.H + 7) / 8);
   const int pairs = nicb * nocb;
-  int nblk_x = (1024 + pairs - 1) / pairs;          // ~4 blocks per CU in total
+  int nblk_x = (512 + pairs - 1) / pairs;           // measured best of 512 / 768 / 1024 / 2048           // one resident round: 256 CUs x 2 blocks (phase-aligned rounds do not overlap)
   if (nblk_x > tiles) nblk_x = tiles;
   if (nblk_x < 1) nblk_x = 1;
   const int tpb = (tiles + nblk_x - 1) / nblk_x;
@@ -205,6 +222,7 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
   if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1 || !a0.part)
     return HCF_ERR_ARG;
   WgradArgs a = a0;
+  a.dbg = getenv("HCF_WG_DBG") ? atoi(getenv("HCF_WG_DBG")) : 0;
   int nicb = 0, cin = 0;
   for (int i = 0; i < a.nsrc; ++i) {
     if ((a.H >> a.src[i].up) << a.src[i].up != a.H || (a.W >> a.src[i].up) << a.src[i].up != a.W) return HCF_ERR_ARG;
@@ -217,8 +235,13 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
   if (need > a.part_cap) return HCF_ERR_NOMEM;
   const int nocb = (a.g.n + 31) >> 5;
   const dim3 grid((unsigned)nblk_x, (unsigned)nicb, (unsigned)nocb);
-  if (a.taps == 9) hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<9>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(wgrad::conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  bool vec = (((a.g.cs | a.g.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.g.p) & 15) == 0);
+  for (int i = 0; i < a.nsrc; ++i)
+    vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
+  if (a.taps == 9 && vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, true>), grid, dim3(256), 0, st, a);
+  else if (a.taps == 9) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, false>), grid, dim3(256), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<1, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<1, false>), grid, dim3(256), 0, st, a);
   const dim3 rgrid((unsigned)((a.taps * 1024 + 255) / 256), (unsigned)nicb, (unsigned)nocb);
   hipLaunchKernelGGL(wgrad::wgrad_reduce_kernel, rgrid, dim3(256), 0, st, a, nblk_x, a.taps);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
