@@ -51,12 +51,6 @@ typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 
 int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle the tall-tile variants, see launch_t)
 
-#ifndef HCF_DBG_NOZPAGE
-#define HCF_DBG_NOZPAGE 0
-#endif
-#ifndef HCF_DBG_NOINTER
-#define HCF_DBG_NOINTER 0
-#endif
 #ifndef HCF_SETPRIO
 #define HCF_SETPRIO 1
 #endif
@@ -113,7 +107,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   // variants keep it off: they are a handful of small launches, and the extra live registers make the 24-channel
   // variant spill. (The wrong pixels once blamed on this combination came from the tail's matrix being read with
   // uniform-address VECTOR loads, see hcf_step_math.h const_table(); tests/test_gpu_f16x3.py::test_large_grid_*.)
-  constexpr bool INTERLEAVE = (TAILC == 0) && !HCF_DBG_NOINTER;
+  constexpr bool INTERLEAVE = (TAILC == 0);
   static_assert(!FUSE2 || NTB == 2, "the fused 1x1 layer needs all 64 channels of the tile in one block");
   constexpr int TAPS = 9, PAD = 1;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
@@ -131,11 +125,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   constexpr int T_BYTES = TAILC ? (TH * TW) * HCS * 4 : 0;
   constexpr int LDS_MAIN = A_BYTES + B_BYTES;
   constexpr int LDS_BYTES = (LDS_MAIN > F2_BYTES ? (LDS_MAIN > T_BYTES ? LDS_MAIN : T_BYTES) : (F2_BYTES > T_BYTES ? F2_BYTES : T_BYTES));
-#ifdef HCF_DBG_BIGLDS
-  __shared__ __attribute__((aligned(16))) char lds[TAILC ? 100000 : LDS_BYTES];
-#else
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-#endif
   char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
@@ -214,7 +204,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
         pidx = (b * Hs + y) * Ws + x;                                                             \
       }                                                                                           \
       gfptr p = sp + (unsigned)(pidx * css); /* launcher guarantees < 2^31 elements per tensor */ \
-      if (!HCF_DBG_NOZPAGE) p = ((okmask >> s) & 1u) ? p : zpage; /* conv zero padding: read a page of zeros */ \
+      p = ((okmask >> s) & 1u) ? p : zpage; /* conv zero padding: read a page of zeros */             \
       f32x4 v;                                                                                    \
       if (VEC) {                                                                                  \
         v = *(gf4ptr)(p);                                                                         \
@@ -237,7 +227,6 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   {                                                                                               \
     f32x4 v = stg[S];                                                                             \
     if (SCALED) { v.x *= in_s; v.y *= in_s; v.z *= in_s; v.w *= in_s; }                            \
-    if (HCF_DBG_NOZPAGE && !((okmask >> (S)) & 1u)) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; } \
     if (stg_valid < 4) {                                                                          \
       v.x = (stg_valid > 0) ? v.x : 0.f;                                                          \
       v.y = (stg_valid > 1) ? v.y : 0.f;                                                          \

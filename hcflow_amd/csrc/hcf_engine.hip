@@ -724,8 +724,7 @@ struct hcf_engine {
     if (getenv("HCF_NO_FUSE_TAIL")) return false;     // debugging aid
     if (taping) return false;
     const Conv& c = s.c[2];
-    const int lim = getenv("HCF_TAIL_CMAX") ? atoi(getenv("HCF_TAIL_CMAX")) : 24;
-    return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= lim;   // the 48-channel variant spills
+    return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= 24;   // the 48-channel variant spills
   }
 
   void run_coupling_net(const Step& s, View z1, const View* u, int H, int W, Scratch& sc, const StepArgs* tail = nullptr) {
@@ -770,13 +769,6 @@ struct hcf_engine {
     a.z = z.all(); a.h = sc.hout.v(0, s.f_out); a.out = z.all();
     a.mat = s.has_mat ? s.mat_inv : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_inv;
     if (can_fuse_tail(s)) {
-      if (getenv("HCF_TAIL_OOP")) {                             // debugging aid: out-of-place tail + copy back
-        Buf tmp = alloc(B_, H, W, s.C);
-        a.out = tmp.all();
-        run_coupling_net(s, step_z1(s, z), u, H, W, sc, &a);
-        HCF_LAUNCH(launch_copy_view(tmp.all(), z.all(), B_, H, W, st));
-        return;
-      }
       run_coupling_net(s, step_z1(s, z), u, H, W, sc, &a);      // conv3's epilogue finishes the step
       return;
     }
