@@ -234,6 +234,42 @@ def gen_grad_fixture(name, preset_name, ref_sr, B, h, w, seed):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_rgrad_fixture(name, preset_name, ref_sr, B, h, w, seed, tau):
+    """Gradients through the REVERSE path (HCFlow_SR_model.optimize_parameters :207-216, the HR pixel loss of the
+    HCFlow+ / ++ recipes): fake_H = netG(lr, eps_std, reverse=True); L1(fake_H, real_H).backward(). The eps draws are
+    captured so that the same sample can be replayed."""
+    cfg = preset(preset_name)
+    net, params = build(ref_sr, cfg, seed)
+    net.train()
+    g = torch.Generator().manual_seed(seed + 43)
+    lr = torch.rand(B, 3, h, w, generator=g)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=g) * 0.6 + 0.2
+    with Capture() as cap:
+        fake = net(lr=lr, z=None, u=None, eps_std=tau, reverse=True)
+    loss = torch.nn.functional.l1_loss(fake, hr)
+    loss.backward()
+    out = {"preset": preset_name, "seed": seed, "lr": np_(lr), "hr": np_(hr), "tau": np.float64(tau),
+           "fake": np_(fake), "loss": np.float64(float(loss.detach()))}
+    for i, e in enumerate(cap.normal):
+        out["eps%d" % i] = np_(e)
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    dig, nfull = [], 0
+    for i, (k, prm) in enumerate(net.named_parameters()):
+        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+        dig.append(grad_digest(gr, i))
+        if gr.size <= 2304:
+            out["g_%d" % i] = gr
+            nfull += 1
+    out["gdigest"] = np.array(dig, dtype=np.float64)
+    frac = float(((fake <= 0) | (fake >= 1)).float().mean())
+    print("  %s loss %.6f clamped %.3f: %d tensors, %d in full, |g| range [%.3e, %.3e]" % (
+        name, float(loss.detach()), frac, len(dig), nfull, min(d[0] for d in dig), max(d[0] for d in dig)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def gen_op_fixture(ref_sr, ref_rs):
     """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
     from models.modules import Basic, thops
@@ -351,6 +387,11 @@ def main():
         gen_grad_fixture("grad_sr4_tiny", "SR_4X_tiny", ref_sr, B=2, h=10, w=12, seed=41)
         gen_grad_fixture("grad_sr8_tiny", "SR_8X_tiny", ref_sr, B=2, h=5, w=6, seed=42)
         if only == "grad":
+            return
+    if only in ("all", "rgrad"):
+        gen_rgrad_fixture("rgrad_sr4_tiny", "SR_4X_tiny", ref_sr, B=2, h=10, w=12, seed=51, tau=0.7)
+        gen_rgrad_fixture("rgrad_sr8_tiny", "SR_8X_tiny", ref_sr, B=2, h=5, w=6, seed=52, tau=0.0)
+        if only == "rgrad":
             return
     gen_op_fixture(ref_sr, ref_rs)
     # reduced-depth nets with the real channel widths, odd-ish spatial sizes, B=2

@@ -216,3 +216,32 @@ def test_nll_gradients_match_reference(name):
     from hcflow_amd.config import param_spec
     grads = [np.zeros(tuple(q[k].shape), np.float32) if q[k].grad is None else q[k].grad.numpy() for k, _, _ in param_spec(cfg)]
     check_grads_against_fixture(g, grads)
+
+
+RGRADS = ["rgrad_sr4_tiny", "rgrad_sr8_tiny"]
+
+
+def rgrad_eps(g):
+    out, i = [], 0
+    while "eps%d" % i in g.files:
+        out.append(t(g["eps%d" % i]))
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("name", RGRADS)
+def test_reverse_path_gradients_match_reference(name):
+    """fake_H = netG(lr, eps_std, reverse=True); L1(fake_H, real_H).backward() (HCFlow_SR_model.py:207-216): the
+    oracle's autograd through the inverse flow (incl. inverse(W.double()), Permutations.py:72-74, and the output
+    clamp) reproduces the reference's parameter gradients."""
+    from hcflow_amd.config import param_spec
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    fake = O.sr_inverse(t(g["lr"]), q, cfg, float(g["tau"]), eps=rgrad_eps(g))
+    assert maxdiff(fake.detach(), g["fake"]) <= 1e-4
+    loss = torch.nn.functional.l1_loss(fake, t(g["hr"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    grads = [np.zeros(tuple(q[k].shape), np.float32) if q[k].grad is None else q[k].grad.numpy() for k, _, _ in param_spec(cfg)]
+    check_grads_against_fixture(g, grads, rtol=5e-4)
