@@ -270,6 +270,58 @@ class _SRNLLStep(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _SRReverseStep(torch.autograd.Function):
+    """``fake_H = netG(lr=, eps_std=, reverse=True)`` with gradients w.r.t. the parameters (the HR pixel / feature /
+    GAN losses of the HCFlow+ / ++ recipes, HCFlow_SR_model.py:207-255): hcf_train_inverse keeps the tape,
+    hcf_train_backward_inverse turns dL/d fake_H into the flat parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, module, lr, tau, seed, clamp, eps, *params):
+        dev = lr.device
+        eng, idx = module._engine_for(dev)
+        cfg = module.cfg
+        B, _, h, w = lr.shape
+        out = torch.empty(B, 3, h * cfg.scale, w * cfg.scale, device=dev, dtype=torch.float32)
+        shapes = eps_shapes(cfg, B, h, w)
+        arr = (C.c_void_p * len(shapes))()
+        keep = []
+        if eps is not None:
+            assert len(eps) == len(shapes)
+            for i, (e, s) in enumerate(zip(eps, shapes)):
+                if e is None:
+                    arr[i] = None
+                    continue
+                e = module._prep(e, dev)
+                assert tuple(e.shape) == tuple(s), (tuple(e.shape), s)
+                keep.append(e)
+                arr[i] = e.data_ptr()
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_train_inverse(eng.handle, lr.data_ptr(), arr, len(shapes), float(tau), int(seed),
+                                           out.data_ptr(), B, h, w, 0 if clamp else _lib.FLAG_NO_CLAMP,
+                                           module._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_train_inverse")
+        ctx.eng, ctx.idx = eng, idx
+        ctx.keep = (lr, keep)
+        ctx.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        eng, idx = ctx.eng, ctx.idx
+        total = sum(n for _, n, _ in ctx.meta)
+        g_out = g_out.to(torch.float32).contiguous()
+        flat = torch.empty(total, device=g_out.device, dtype=torch.float32)
+        with torch.cuda.device(idx):
+            rc = eng.lib.hcf_train_backward_inverse(eng.handle, g_out.data_ptr(), flat.data_ptr(), total,
+                                                    C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+        _lib.check(rc, eng.handle, "hcf_train_backward_inverse")
+        grads, off = [], 0
+        for shape, n, need in ctx.meta:
+            grads.append(flat[off:off + n].view(shape) if need else None)
+            off += n
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
 # ------------------------------------------------------------------ engine-backed top modules
 class _EngineModule(nn.Module):
     """Shared plumbing: parameter upload / repack tracking and raw-pointer calls into the C ABI."""
@@ -337,9 +389,8 @@ class _EngineModule(nn.Module):
     def _check_inference(self, reverse=False):
         if self._wants_grad():
             raise NotImplementedError(
-                "hcflow_amd builds the backward pass of the SR NLL objective (netG(hr=, lr=, reverse=False)); "
-                "gradients through %s are not built yet (SURVEY.md section 8f). Call under torch.no_grad()."
-                % ("the reverse (sampling) path" if reverse else "this forward path"))
+                "hcflow_amd builds the backward passes of the SR nets (NLL objective and sampling path); gradients "
+                "through the rescaling net are not built yet (SURVEY.md section 8f). Call under torch.no_grad().")
         if self.training and reverse and self._pending_actnorms():
             raise NotImplementedError(
                 "un-initialised ActNorm layers in train() mode on the REVERSE path: the reference would fit them to "
@@ -379,6 +430,16 @@ class _EngineModule(nn.Module):
         return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
     def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None):
+        if self._wants_grad() and self.cfg.sr:
+            if self.training and self._pending_actnorms():
+                raise NotImplementedError(
+                    "un-initialised ActNorm layers in train() mode on the REVERSE path: run one forward (hr -> z) pass "
+                    "first, load a checkpoint / set .inited = True, or call .eval().")
+            dev = next(self.parameters()).device
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            tau = 0.0 if eps_std is None else float(eps_std)
+            return _SRReverseStep.apply(self, self._prep(lr, dev), tau, seed, bool(clamp), eps, *list(self.parameters()))
         self._check_inference(reverse=True)
         dev = next(self.parameters()).device
         eng, idx = self._engine_for(dev)

@@ -78,6 +78,7 @@ struct WgradArgs {
   int B, H, W;
   int taps;                // 9 (3x3, pad 1) or 1
   float* dw;               // [cout][cin_total][taps], accumulated (caller zero-initialises)
+  int negate;              // dW -= ... instead of += (the inverse 1x1 conv's weight gradient)
   float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
   size_t part_cap;         // capacity of `part` in floats
   int cin_total, tpb;      // set by the launcher
@@ -162,12 +163,31 @@ struct StepBwdArgs {
 int launch_step_couple_bwd(const StepBwdArgs& a, hipStream_t st);
 int launch_step_head_bwd(const StepBwdArgs& a, hipStream_t st);
 
+// backward of one INVERSE flow step (FlowStep.reverse_flow, FlowStep.py:53-64):  z -> zc = coupling^-1(z, h) -> y = W^-1 zc
+// -> x = y e^-s - b. Given gx: gy = gx e^-s, gzc = W^-T gy, gz (coupling^-1 backward), gh; sums for bias / logs;
+// y and gzc are materialised for the 1x1 weight-gradient kernel (dW = -sum gzc y^T).
+struct StepInvBwdArgs {
+  int B, H, W, C, ns, mode;
+  View gx, x, zc, h;           // in
+  View gz, gh, gzc, y;         // out (=)
+  const float* matInvT;        // [CMAX][CMAX], row j = column j of W^-1, or nullptr
+  const float* an_bias;        // b
+  const float* mul_fwd;        // e^s
+  const float* mul_inv;        // e^-s
+  float* g_bias;               // [C] +=
+  float* g_logs;               // [C] +=
+};
+int launch_step_inv_bwd(const StepInvBwdArgs& a, hipStream_t st);
+int launch_mask_unit_range(View z, View g, int B, int H, int W, hipStream_t st);      // g = (0 <= z <= 1) ? g : 0
+
 struct PriorBwdArgs {
   int B, H, W, C;          // C = channels of the latent; h has 2C (mean = h[0::2], logs = h[1::2])
   View a, h, ga, gh;       // ga (=), gh (=)
   float gobj;
 };
 int launch_gauss_logp_bwd(const PriorBwdArgs& a, hipStream_t st);
+// a = mean + e^logs * eps (SR prior sample): gh[2c] = ga[c], gh[2c+1] = ga[c] * (a[c] - mean)   (ga in, gh out)
+int launch_gauss_sample_bwd(const PriorBwdArgs& a, hipStream_t st);
 // d/dz of logp(lr; mean := Quant(z), logs = -6) with the straight-through Quant: gz += gobj * (lr - q(z)) * e^12
 int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, int W, float gobj, hipStream_t st);
 int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st);      // out += alpha * in

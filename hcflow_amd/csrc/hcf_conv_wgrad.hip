@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     for (int j = 0; j < 8; ++j) s8[j] += p[(size_t)(b + j) * stride];
   for (; b < nx; ++b) s8[b & 7] += p[(size_t)b * stride];
   const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += s;
+  a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += a.negate ? -s : s;
 }
 
 }  // namespace wgrad

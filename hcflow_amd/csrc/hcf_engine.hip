@@ -64,6 +64,7 @@ struct Step {
   std::string wkey;                 // "....permute.weight" (or "")
   float *mat_fwdT = nullptr;        // training: W^T padded [cmax][cmax] (gza = W^T gzb)
   float *winvT = nullptr;           // training: W^-T, [C][C] unpadded (d slogdet / dW)
+  float *mat_invT = nullptr;        // training: (W^-1)^T padded [cmax][cmax] (reverse path: gzc = W^-T gy)
 };
 
 struct Rdb { Conv c[5]; };
@@ -433,14 +434,16 @@ struct hcf_engine {
       s.mat_inv = upload(wi);
       s.mat_fwd = upload(wf);
       {
-        std::vector<float> wt((size_t)M * M, 0.f), it((size_t)C * C, 0.f);
+        std::vector<float> wt((size_t)M * M, 0.f), it((size_t)C * C, 0.f), itp((size_t)M * M, 0.f);
         for (int r = 0; r < C; ++r)
           for (int c = 0; c < C; ++c) {
             wt[(size_t)c * M + r] = W[(size_t)r * C + c];
             it[(size_t)c * C + r] = (float)inv[(size_t)r * C + c];
+            itp[(size_t)c * M + r] = (float)inv[(size_t)r * C + c];
           }
         s.mat_fwdT = upload(wt);
         s.winvT = upload(it);
+        s.mat_invT = upload(itp);
       }
       s.lad = lad;
       s.ld_const += lad;
@@ -1240,7 +1243,18 @@ int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const 
 
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream) {
   if (!e || numel < 0) return HCF_ERR_ARG;
-  return e->run_backward(grad_nll, dparams, (size_t)numel, (hipStream_t)stream);
+  return e->run_backward(1, grad_nll, nullptr, dparams, (size_t)numel, (hipStream_t)stream);
+}
+
+int hcf_train_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                      float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream) {
+  if (!e || !lr || !out_hr || B < 1 || h < 1 || w < 1) return HCF_ERR_ARG;
+  return e->run_train_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags, (hipStream_t)stream);
+}
+
+int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, hcf_stream_t stream) {
+  if (!e || numel < 0) return HCF_ERR_ARG;
+  return e->run_backward(2, 1.f, grad_out, dparams, (size_t)numel, (hipStream_t)stream);
 }
 
 int hcf_bind_param_device(hcf_engine* e, const char* key, const float* dev_ptr) {

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
   const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
   float y[CMAX];
   step_tail_inverse_pixel<CMAX>(z, hp, a.C, a.ns, a.mode, a.mat, a.an_bias, a.an_mul, y);
+  if (a.aux.p) store_pixel<CMAX>(a.aux, pix, a.C, z);          // training tape: z after coupling^-1 (input of W^-1)
   store_pixel<CMAX>(a.out, pix, a.C, y);
 }
 

@@ -201,6 +201,115 @@ int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, i
   HCF_RET_T();
 }
 
+// ---- inverse flow step backward (one thread per pixel) ---------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void step_inv_bwd_kernel(const StepInvBwdArgs a) {
+  __shared__ float sh[2][CMAX];
+  if (threadIdx.x < CMAX) { sh[0][threadIdx.x] = 0.f; sh[1][threadIdx.x] = 0.f; }
+  __syncthreads();
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < hw) {
+    const size_t pix = (size_t)blockIdx.y * hw + i;
+    float gx[CMAX], x[CMAX], gy[CMAX], y[CMAX], gzc[CMAX];
+    load_pixel<CMAX>(a.gx, pix, a.C, gx);
+    load_pixel<CMAX>(a.x, pix, a.C, x);
+    const step_cptr b = const_table(a.an_bias), mf = const_table(a.mul_fwd), mi = const_table(a.mul_inv);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      const float xb = x[c] + b[c];                 // = y e^-s
+      y[c] = xb * mf[c];
+      gy[c] = gx[c] * mi[c];
+      if (c < a.C) {
+        atomicAdd(&sh[0][c], -gx[c]);               // x = y e^-s - b
+        atomicAdd(&sh[1][c], -gx[c] * xb);
+      }
+    }
+    if (a.matInvT) {
+      matvec<CMAX>(const_table(a.matInvT), gy, gzc);
+    } else {
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) gzc[c] = gy[c];
+    }
+    store_pixel<CMAX>(a.y, pix, a.C, y);
+    store_pixel<CMAX>(a.gzc, pix, a.C, gzc);
+    // coupling^-1 backward: zc2 = z2 e^-ls - shift
+    const float* zp = a.zc.p + pix * a.zc.cs + a.zc.c0;
+    const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+    float* oh = a.gh.p + pix * a.gh.cs + a.gh.c0;
+    float gz[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      gz[c] = gzc[c];
+      if (a.mode == CPL_AFFINE && c >= a.ns && c < a.C) {
+        const int j = c - a.ns;
+        const float shift = hp[2 * j], scale = hp[2 * j + 1];
+        const float e = expf(-logscale_of(scale));
+        gz[c] = gzc[c] * e;
+        oh[2 * j] = -gzc[c];
+        const float gls = -gzc[c] * (zp[c] + shift);               // d(z2 e^-ls)/d ls = -(zc2 + shift)
+        oh[2 * j + 1] = gls * (0.636f / (1.f + 4.f * scale * scale));
+      }
+    }
+    if (a.mode != CPL_AFFINE)
+      for (int c = 0; c < 3; ++c) oh[c] = -gzc[c];                  // z[:3] -= h
+    store_pixel<CMAX>(a.gz, pix, a.C, gz);
+  }
+  __syncthreads();
+  if (threadIdx.x < a.C) {
+    atomicAdd(a.g_bias + threadIdx.x, sh[0][threadIdx.x]);
+    atomicAdd(a.g_logs + threadIdx.x, sh[1][threadIdx.x]);
+  }
+}
+
+int launch_step_inv_bwd(const StepInvBwdArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1 || !a.g_bias || !a.g_logs) return HCF_ERR_ARG;
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  if (a.C <= 8) hipLaunchKernelGGL((step_inv_bwd_kernel<8>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 12) hipLaunchKernelGGL((step_inv_bwd_kernel<12>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 24) hipLaunchKernelGGL((step_inv_bwd_kernel<24>), grid, dim3(256), 0, st, a);
+  else if (a.C <= 48) hipLaunchKernelGGL((step_inv_bwd_kernel<48>), grid, dim3(256), 0, st, a);
+  else return HCF_ERR_UNSUPPORTED;
+  HCF_RET_T();
+}
+
+// ---- prior sample backward (SR: logs = h[1::2]) ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gauss_sample_bwd_kernel(const PriorBwdArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* ap = a.a.p + pix * a.a.cs + a.a.c0;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  const float* ga = a.ga.p + pix * a.ga.cs + a.ga.c0;
+  float* gh = a.gh.p + pix * a.gh.cs + a.gh.c0;
+  for (int c = 0; c < a.C; ++c) {
+    gh[2 * c] = ga[c];                               // a = mean + e^logs eps
+    gh[2 * c + 1] = ga[c] * (ap[c] - hp[2 * c]);     // d a / d logs = e^logs eps = a - mean
+  }
+}
+int launch_gauss_sample_bwd(const PriorBwdArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  hipLaunchKernelGGL(gauss_sample_bwd_kernel, grid, dim3(256), 0, st, a);
+  HCF_RET_T();
+}
+
+__global__ __launch_bounds__(256) void mask_unit_range_kernel(View z, View g, int hw) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = g.n;
+  if (e >= (long long)hw * n) return;
+  const int c = (int)(e % n);
+  const size_t pix = (size_t)blockIdx.y * hw + (size_t)(e / n);
+  const float v = z.p[pix * z.cs + z.c0 + c];
+  if (!(v >= 0.f && v <= 1.f)) g.p[pix * g.cs + g.c0 + c] = 0.f;      // torch.clamp(x, 0, 1) backward
+}
+int launch_mask_unit_range(View z, View g, int B, int H, int W, hipStream_t st) {
+  if (z.n != g.n) return HCF_ERR_ARG;
+  const long long per = (long long)H * W * g.n;
+  hipLaunchKernelGGL(mask_unit_range_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)B), dim3(256), 0, st, z, g, H * W);
+  HCF_RET_T();
+}
+
 // ---- small helpers ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_view_kernel(View in, View out, int hw, float alpha) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -147,6 +147,15 @@ int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const 
                          float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
 
+/* Gradients through the REVERSE (sampling) path (reference: the HR pixel / feature / GAN losses of the HCFlow+ / ++
+ * recipes, HCFlow_SR_model.py:207-255: `fake_H = netG(lr=, eps_std=, reverse=True)` followed by a loss on fake_H and
+ * backward()). hcf_train_inverse = hcf_inverse (same arguments and output) with a tape; hcf_train_backward_inverse
+ * takes dL/d(out_hr) (device [B,3,H,W], the clamp's gradient mask is applied inside) and writes dL/d(parameter) for
+ * every parameter like hcf_train_backward. */
+int hcf_train_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                      float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
+int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, hcf_stream_t stream);
+
 /* In-place parameter updates on the GPU (optimiser steps; reference: base_model / HCFlow_SR_model keep netG's
  * parameters on the device and Adam updates them in place, HCFlow_SR_model.py:108-125,202). After hcf_finalize,
  * hcf_bind_param_device tells the engine where each parameter lives in DEVICE memory (fp32, contiguous, same shape

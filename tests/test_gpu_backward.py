@@ -254,3 +254,74 @@ def test_device_refresh_equals_host_repack():
     scale = max(1.0, float(inv_b.abs().max()))
     assert float((inv_a - inv_b).abs().max()) <= 2e-5 * scale
     assert float((inv_a16 - inv_b16).abs().max()) <= 2e-5 * scale
+
+
+RGRADS = ["rgrad_sr4_tiny", "rgrad_sr8_tiny"]
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+@pytest.mark.parametrize("name", RGRADS)
+def test_reverse_path_gradients_match_reference(name, precision):
+    """fake_H = netG(lr=, eps_std=, reverse=True); L1(fake_H, real_H).backward() (HCFlow_SR_model.py:207-216, the HR
+    pixel loss of the HCFlow+ / ++ recipes) through the drop-in module: fake_H, the loss and d loss / d parameter for
+    every tensor against the reference-generated fixture (same captured eps)."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import param_spec
+    from tests.util import load_golden, params_for, t
+    from tests.test_oracle_golden import check_grads_against_fixture, rgrad_eps
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").train().set_precision(precision)
+    fake = net(lr=t(g["lr"]).cuda(), z=None, u=None, eps_std=float(g["tau"]), reverse=True,
+               eps=[e.cuda() for e in rgrad_eps(g)])
+    assert float((fake.detach().cpu() - t(g["fake"])).abs().max()) <= 1e-4
+    loss = F.l1_loss(fake, t(g["hr"]).cuda())
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5
+    loss.backward()
+    sd = dict(net.named_parameters())
+    grads = [np.zeros(tuple(sd[k].shape), np.float32) if sd[k].grad is None else sd[k].grad.cpu().numpy()
+             for k, _, _ in param_spec(cfg)]
+    assert all(np.isfinite(x).all() for x in grads)
+    check_grads_against_fixture(g, grads, rtol=5e-4)
+
+
+def test_hcflow_plus_style_step_mixes_both_tapes_and_a_torch_discriminator():
+    """The HCFlow+ / ++ generator step (HCFlow_SR_model.optimize_parameters :189-255): NLL backward + optimiser step,
+    then the reverse pass at eps_std = 0 with an L1 pixel loss, then a sampled fake_H scored by a stock-PyTorch
+    discriminator; every phase gives finite gradients and the pixel phase lowers its loss."""
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train().set_precision("f16x3")
+    g = torch.Generator().manual_seed(15)
+    hr = torch.rand(2, 3, 64, 64, generator=g).cuda() * 0.6 + 0.2
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    disc = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, 2, 1), torch.nn.LeakyReLU(0.2), torch.nn.Conv2d(8, 1, 3, 2, 1)).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+    pix = []
+    try:
+        for it in range(3):
+            opt.zero_grad()
+            _, nll = net(hr=hr, lr=lr, u=None, reverse=False)
+            (1e-3 * nll).backward()
+            opt.step()
+            opt.zero_grad()
+            fake = net(lr=lr, z=None, u=None, eps_std=0.0, reverse=True)
+            l_pix = F.l1_loss(fake, hr)
+            l_pix.backward()
+            assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+            opt.step()
+            pix.append(float(l_pix.detach()))
+            opt.zero_grad()
+            fake = net(lr=lr, z=None, u=None, eps_std=0.8, reverse=True)
+            l_gan = F.softplus(-disc(fake)).mean()                 # generator side of a non-saturating GAN loss
+            l_gan.backward()
+            assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in net.parameters())
+            assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+        assert pix[-1] < pix[0], pix
+    finally:
+        net.set_precision("exact")
