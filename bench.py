@@ -97,8 +97,22 @@ def main():
     out_all = torch.empty(world * B, 3, h * cfg.scale, h * cfg.scale, device=dev) if world > 1 else None
     torch.manual_seed(rank)
 
-    def step():
-        out = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+    roundtrip = not cfg.sr          # config 4: rescaling forward -> Quant -> inverse (HCFlow_Rescaling_model.py:306-324)
+    hr_in = torch.rand(B, 3, h * cfg.scale, h * cfg.scale, generator=g).to(dev) if roundtrip else None
+
+    last = {}
+
+    def step(fixed_lrq=None):
+        if roundtrip:
+            if fixed_lrq is None:
+                lr_hat, _, _ = net(hr=hr_in, reverse=False)
+                lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.
+            else:
+                lrq = fixed_lrq
+            last["lrq"] = lrq
+            out = net(lr=lrq, z=None, u=None, eps_std=args.tau, reverse=True)
+        else:
+            out = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
         if world > 1:
             dist.all_gather_into_tensor(out_all, out)     # RCCL over xGMI: output batch only
         return out
@@ -125,19 +139,25 @@ def main():
     if args.precision != "exact" and not args.no_exact_check:
         with torch.no_grad():
             torch.manual_seed(1234)
-            y_fast = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+            y_fast = step()
+            lrq_fast = last.get("lrq")
             net.set_precision("exact")
             torch.manual_seed(1234)
-            y_exact = net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)     # also warms the exact path
+            if roundtrip:       # same quantised LR for both: a 1e-6 deviation before Quant can flip a 1/255 level
+                lr_e, _, _ = net(hr=hr_in, reverse=False)
+                quant_flips = float(((torch.clamp(lr_e, 0, 1) * 255.).round() / 255. != lrq_fast).float().mean())
+            y_exact = step(lrq_fast)                                                 # also warms the exact path
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            net(lr=lr, z=None, u=None, eps_std=args.tau, reverse=True)
+            step()
             torch.cuda.synchronize()
             dte = time.perf_counter() - t1
             net.set_precision(args.precision)
         exact = {"max_abs_diff_vs_exact_f32": float((y_fast - y_exact).abs().max()),
                  "exact_f32_images_per_s_per_gpu": round(B / dte, 3), "tolerance": 1e-4,
                  "range_fallbacks": net.engine().fallback_count()}
+        if roundtrip:
+            exact["quantised_lr_levels_flipped_frac"] = quant_flips
         del y_fast, y_exact
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -200,15 +220,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, params, h, args.tau, args.cpu_passes)
         line = {
-            "metric": "HR images/sec (inverse sample) DIV2K x4 160px LR", "value": round(img_s, 4),
+            "metric": ("HR images/sec (inverse sample) DIV2K x4 160px LR" if cfg.sr else
+                       "HR images/sec (rescaling x4 forward + inverse round trip)"), "value": round(img_s, 4),
             "unit": "HR images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.precision == "exact" else "f32 via f16x3 split (hi/lo f16 products, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "%s inverse sampling (netG reverse=True), batch %d/GPU, LR %dx%d -> HR %dx%d, "
+            "config": {"workload": "%s %s, batch %d/GPU, LR %dx%d -> HR %dx%d, "
                                    "tau=%.1f, eps on device, output all-gather over RCCL for N>1"
-                                   % (args.preset, B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
+                                   % (args.preset, "forward -> Quant -> inverse round trip" if roundtrip else
+                                      "inverse sampling (netG reverse=True)", B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
                        "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
