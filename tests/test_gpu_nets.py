@@ -299,3 +299,24 @@ def test_config4_rescaling_shard_roundtrip(precision):
             assert bool(torch.isfinite(rt).all()) and float(rt.min()) >= 0.0 and float(rt.max()) <= 1.0
     finally:
         net.set_precision("exact")
+
+
+def test_full_size_div2k_validation_image_ragged_shape():
+    """A whole DIV2K validation LR image as test_HCFlow.py feeds it (batch 1, 339 x 510 -> HR 1356 x 2040: odd sizes,
+    no multiple of the 8 x 32 tile): f16x3 within 1e-4 of the exact kernels, tau = 0 reproducible, finite."""
+    cfg, net = _full_net("SR_DF2K_4X", 1234)
+    g = torch.Generator().manual_seed(80)
+    lr = torch.rand(1, 3, 339, 510, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.9 for s in eps_shapes(cfg, 1, 339, 510)]
+    with torch.no_grad():
+        ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.9, eps=eps, clamp=False)
+        assert tuple(ex.shape) == (1, 3, 1356, 2040) and bool(torch.isfinite(ex).all())
+        net.set_precision("f16x3")
+        try:
+            fa = net.reverse_flow_diracLR(lr, None, None, eps_std=0.9, eps=eps, clamp=False)
+            d0 = net(lr=lr, eps_std=0.0, reverse=True)
+            d1 = net(lr=lr, eps_std=0.0, reverse=True)
+        finally:
+            net.set_precision("exact")
+    assert maxdiff(fa, ex) <= 1e-4 * max(1.0, float(ex.abs().max()))
+    assert torch.equal(d0, d1) and float(d0.min()) >= 0.0 and float(d0.max()) <= 1.0
