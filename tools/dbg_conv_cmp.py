@@ -15,6 +15,9 @@ x = torch.randn(B, cin, H, W, generator=g).cuda()
 w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
 ops.set_precision("exact")
 ex = ops.conv2d([x], w)
+if os.environ.get("HCF_ABLATE"):
+    from hcflow_amd import _lib
+    assert _lib.load().hcf_debug_set_ablation(int(os.environ["HCF_ABLATE"])) == 0
 ops.set_precision("f16x3")
 outs = [ops.conv2d([x], w) for _ in range(reps)]
 ops.set_precision("exact")
