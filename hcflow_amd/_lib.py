@@ -27,7 +27,7 @@ SYMBOLS = [
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
     "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
-    "hcf_train_inverse", "hcf_train_backward_inverse",
+    "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
 ]
 
 
@@ -89,6 +89,8 @@ def load() -> C.CDLL:
     lib.hcf_profile_convs.argtypes = [vp, C.c_int]
     lib.hcf_conv_time_ms.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
+    lib.hcf_metric_psnr_ssim.argtypes = [fp, fp, i32, i32, i32, i32, i32, fp, vp]
+    lib.hcf_metric_imresize_down.argtypes = [fp, i32, i32, i32, i32, fp, vp]
     lib.hcf_train_inverse.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, fp, i32, i32, i32, C.c_uint32, vp]
     lib.hcf_train_backward_inverse.argtypes = [vp, fp, fp, i64, vp]
     lib.hcf_bind_param_device.argtypes = [vp, C.c_char_p, fp]

@@ -186,6 +186,18 @@ int hcf_profile_convs(hcf_engine* e, int enable);
 int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t kind, int32_t reset, double* total_ms,
                      int64_t* launches, double* flops, double* bytes);
 
+/* ---- validation metrics around the path (reference: the per-image metric block of test_HCFlow.py:103-182) ------
+ * hcf_metric_psnr_ssim: util.tensor2img (utils/util.py:790-816) on gt and sr, then util.calculate_psnr_ssim(gt, sr,
+ * crop_border) (:898-982; Y channel as data/util.py:209-230) and, for scale > 1, the same on
+ * imresize(gt, 1/scale), imresize(sr, 1/scale) with crop 0 (utils/imresize.py, MATLAB bicubic with antialiasing).
+ * gt, sr: device [B,3,H,W] RGB fp32; out: HOST double [B][8] = psnr, ssim, psnr_y, ssim_y, then the four
+ * down-scaled ("bicHR") values (0 when scale <= 1). float64 arithmetic. hcf_metric_imresize_down returns the
+ * down-scaled tensor2img image itself (HOST double [B][3 (B,G,R)][ceil(H/scale)][ceil(W/scale)], 0..255 units). */
+int hcf_metric_psnr_ssim(const float* gt, const float* sr, int32_t B, int32_t H, int32_t W, int32_t crop_border,
+                         int32_t scale, double* out, hcf_stream_t stream);
+int hcf_metric_imresize_down(const float* x, int32_t B, int32_t H, int32_t W, int32_t scale, double* out,
+                             hcf_stream_t stream);
+
 /* ---- per-op entry points (unit parity tests; tensors are device NCHW fp32) ------------------- */
 /* F.conv2d(x, w, stride 1, padding k/2) with the fused epilogue
  *   y = res2 + rs2 * (res1 + rs1 * act((conv + bias) * scale))

@@ -270,6 +270,50 @@ def gen_rgrad_fixture(name, preset_name, ref_sr, B, h, w, seed, tau):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_metrics_fixture():
+    """Validation metrics: the reference's imresize (pure numpy), calculate_psnr and bgr2ycbcr run here; the
+    cv2-based SSIM cannot (no OpenCV in this image) and stays unpinned (oracle/metrics_oracle.py)."""
+    import types
+    import importlib.util as ilu
+    spec0 = ilu.spec_from_file_location("ref_utils_imresize", os.path.join(REF, "utils", "imresize.py"))
+    im = ilu.module_from_spec(spec0)
+    spec0.loader.exec_module(im)
+    imresize = im.imresize
+    for name in ("cv2", "natsort", "torchvision", "torchvision.utils"):       # only imported at module level
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision.utils"].make_grid = None
+    real_util = sys.modules.pop("utils.util", None)                            # drop the opt_get stub, load the real file
+    spec = ilu.spec_from_file_location("ref_utils_util", os.path.join(REF, "utils", "util.py"))
+    ru = ilu.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(ru)
+    finally:
+        if real_util is not None:
+            sys.modules["utils.util"] = real_util
+    spec2 = ilu.spec_from_file_location("ref_data_util", os.path.join(REF, "data", "util.py"))
+    du = ilu.module_from_spec(spec2)
+    spec2.loader.exec_module(du)
+    rs = np.random.RandomState(7)
+    out = {}
+    for tag, (h, w) in {"a": (48, 64), "b": (37, 53)}.items():
+        gt = rs.rand(3, h, w).astype(np.float32)
+        sr = np.clip(gt + rs.randn(3, h, w).astype(np.float32) * 0.05, -0.1, 1.1)
+        out["gt_" + tag], out["sr_" + tag] = gt, sr
+        g8 = np.transpose(np.clip(gt, 0, 1)[[2, 1, 0]], (1, 2, 0))
+        s8 = np.transpose(np.clip(sr, 0, 1)[[2, 1, 0]], (1, 2, 0))
+        g8 = (g8 * 255.0).round().astype(np.uint8) / 255.        # tensor2img(...) / 255.  (uint8 -> float64, test_HCFlow.py:139-142)
+        s8 = (s8 * 255.0).round().astype(np.uint8) / 255.
+        out["psnr_" + tag] = np.float64(ru.calculate_psnr(g8 * 255, s8 * 255))
+        out["y_" + tag] = du.bgr2ycbcr(g8.copy(), only_y=True)
+        out["psnr_y_" + tag] = np.float64(ru.calculate_psnr(du.bgr2ycbcr(g8.copy(), only_y=True) * 255,
+                                                            du.bgr2ycbcr(s8.copy(), only_y=True) * 255))
+        out["down4_" + tag] = imresize(g8.astype(np.float64), 0.25)
+        out["down2_" + tag] = imresize(s8.astype(np.float64), 0.5)
+    path = os.path.join(HERE, "metrics.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def gen_op_fixture(ref_sr, ref_rs):
     """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
     from models.modules import Basic, thops
@@ -377,6 +421,10 @@ def main():
     torch.set_num_threads(8)
     ref_sr, ref_rs = import_reference()
     only = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if only in ("all", "metrics"):
+        gen_metrics_fixture()
+        if only == "metrics":
+            return
     if only in ("all", "aninit"):
         gen_aninit_fixture("aninit_sr4_tiny", "SR_4X_tiny", ref_sr, ref_rs, B=2, h=10, w=12, seed=31)
         gen_aninit_fixture("aninit_sr8_tiny", "SR_8X_tiny", ref_sr, ref_rs, B=2, h=5, w=6, seed=32)
