@@ -314,6 +314,49 @@ def gen_metrics_fixture():
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_rescale_grad_fixture(name, preset_name, ref_rs, B, h, w, seed):
+    """One generator step of HCFlow_Rescaling_model.optimize_parameters (:212-238) with the shipped weights of
+    train_Rescaling_DF2K_4X_HCFlow.yml (:91-98): l = 5e-2 MSE(fake_LR, LR) + 1e-5 mean(z^2) + L1(fake_H, HR), where
+    fake_H = netG(lr=Quant(fake_LR), eps_std=1.0, reverse=True); the eps draws are captured."""
+    from models.modules.Basic import Quantization
+    cfg = preset(preset_name)
+    net, params = build(ref_rs, cfg, seed)
+    net.train()
+    g = torch.Generator().manual_seed(seed + 47)
+    hr = torch.rand(B, 3, h * 4, w * 4, generator=g) * 0.8 + 0.1
+    lr = torch.nn.functional.avg_pool2d(hr, 4)
+    fake_lr, z1, z2 = net(hr=hr, lr=lr, u=None, reverse=False)
+    l_lr = 5e-2 * torch.nn.functional.mse_loss(fake_lr, lr)
+    l_z = 1e-5 * (torch.cat([z1.flatten(), z2.flatten()], 0) ** 2).mean()
+    q = Quantization()(fake_lr)
+    with Capture() as cap:
+        fake_h = net(lr=q, z=None, u=None, eps_std=1.0, reverse=True)
+    l_hr = 1.0 * torch.nn.functional.l1_loss(fake_h, hr)
+    total = l_lr + l_z + l_hr
+    total.backward()
+    out = {"preset": preset_name, "seed": seed, "hr": np_(hr), "lr": np_(lr), "fake_lr": np_(fake_lr), "z1": np_(z1),
+           "z2": np_(z2), "fake_h": np_(fake_h), "l_lr": np.float64(float(l_lr.detach())),
+           "l_z": np.float64(float(l_z.detach())), "l_hr": np.float64(float(l_hr.detach()))}
+    for i, e in enumerate(cap.normal):
+        out["eps%d" % i] = np_(e)
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    dig, nfull = [], 0
+    for i, (k, prm) in enumerate(net.named_parameters()):
+        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+        dig.append(grad_digest(gr, i))
+        if gr.size <= 2304:
+            out["g_%d" % i] = gr
+            nfull += 1
+    out["gdigest"] = np.array(dig, dtype=np.float64)
+    print("  %s l_lr %.3e l_z %.3e l_hr %.4f: %d tensors, %d in full, |g| range [%.3e, %.3e]" % (
+        name, float(l_lr.detach()), float(l_z.detach()), float(l_hr.detach()), len(dig), nfull,
+        min(d[0] for d in dig), max(d[0] for d in dig)))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def gen_op_fixture(ref_sr, ref_rs):
     """Per-op pins straight from the reference's modules (SURVEY.md 8c 'Per-op pins')."""
     from models.modules import Basic, thops
@@ -440,6 +483,10 @@ def main():
         gen_rgrad_fixture("rgrad_sr4_tiny", "SR_4X_tiny", ref_sr, B=2, h=10, w=12, seed=51, tau=0.7)
         gen_rgrad_fixture("rgrad_sr8_tiny", "SR_8X_tiny", ref_sr, B=2, h=5, w=6, seed=52, tau=0.0)
         if only == "rgrad":
+            return
+    if only in ("all", "rescale_grad"):
+        gen_rescale_grad_fixture("grad_rescale_tiny", "Rescaling_4X_tiny", ref_rs, B=2, h=10, w=12, seed=61)
+        if only == "rescale_grad":
             return
     gen_op_fixture(ref_sr, ref_rs)
     # reduced-depth nets with the real channel widths, odd-ish spatial sizes, B=2

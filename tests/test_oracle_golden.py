@@ -245,3 +245,32 @@ def test_reverse_path_gradients_match_reference(name):
     loss.backward()
     grads = [np.zeros(tuple(q[k].shape), np.float32) if q[k].grad is None else q[k].grad.numpy() for k, _, _ in param_spec(cfg)]
     check_grads_against_fixture(g, grads, rtol=5e-4)
+
+
+def rescale_step_loss(fwd, inv, hr, lr, eps):
+    """The generator loss of HCFlow_Rescaling_model.optimize_parameters (:212-238) with the shipped weights
+    (train_Rescaling_DF2K_4X_HCFlow.yml:91-98); ``fwd(hr) -> (fake_lr, z1, z2)``, ``inv(lr_q, eps) -> fake_h``."""
+    F = torch.nn.functional
+    fake_lr, z1, z2 = fwd(hr)
+    l_lr = 5e-2 * F.mse_loss(fake_lr, lr)
+    l_z = 1e-5 * (torch.cat([z1.flatten(), z2.flatten()], 0) ** 2).mean()
+    q = (torch.clamp(fake_lr, 0, 1) * 255.).round() / 255.
+    q = fake_lr + (q - fake_lr).detach()                       # Basic.Quant: straight-through (Basic.py:186-196)
+    fake_h = inv(q, eps)
+    l_hr = F.l1_loss(fake_h, hr)
+    return l_lr, l_z, l_hr, fake_lr, fake_h
+
+
+def test_rescaling_step_gradients_match_reference():
+    from hcflow_amd.config import param_spec
+    g = load_golden("grad_rescale_tiny")
+    cfg, p = params_for(g)
+    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in p.items()}
+    l_lr, l_z, l_hr, fake_lr, fake_h = rescale_step_loss(
+        lambda x: O.rescale_forward(x, q, cfg), lambda x, e: O.rescale_inverse(x, q, cfg, 1.0, eps=e),
+        t(g["hr"]), t(g["lr"]), rgrad_eps(g))
+    assert maxdiff(fake_lr.detach(), g["fake_lr"]) <= 1e-4 and maxdiff(fake_h.detach(), g["fake_h"]) <= 1e-4
+    assert abs(float(l_hr.detach()) - float(g["l_hr"])) <= 1e-5 and abs(float(l_lr.detach()) - float(g["l_lr"])) <= 1e-7
+    (l_lr + l_z + l_hr).backward()
+    grads = [np.zeros(tuple(q[k].shape), np.float32) if q[k].grad is None else q[k].grad.numpy() for k, _, _ in param_spec(cfg)]
+    check_grads_against_fixture(g, grads, rtol=5e-4)
