@@ -28,6 +28,7 @@ SYMBOLS = [
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
     "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
+    "hcf_train_select_tape", "hcf_train_forward_rescale", "hcf_train_backward_rescale",
 ]
 
 
@@ -92,7 +93,10 @@ def load() -> C.CDLL:
     lib.hcf_metric_psnr_ssim.argtypes = [fp, fp, i32, i32, i32, i32, i32, fp, vp]
     lib.hcf_metric_imresize_down.argtypes = [fp, i32, i32, i32, i32, fp, vp]
     lib.hcf_train_inverse.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, fp, i32, i32, i32, C.c_uint32, vp]
-    lib.hcf_train_backward_inverse.argtypes = [vp, fp, fp, i64, vp]
+    lib.hcf_train_backward_inverse.argtypes = [vp, fp, fp, i64, fp, vp]
+    lib.hcf_train_select_tape.argtypes = [vp, i32]
+    lib.hcf_train_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, C.c_uint32, vp]
+    lib.hcf_train_backward_rescale.argtypes = [vp, fp, fp, fp, fp, i64, vp]
     lib.hcf_bind_param_device.argtypes = [vp, C.c_char_p, fp]
     lib.hcf_refresh_from_device.argtypes = [vp, vp]
     lib.hcf_train_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]

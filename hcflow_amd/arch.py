@@ -244,6 +244,7 @@ class _SRNLLStep(torch.autograd.Function):
         nll = torch.empty(1, device=dev)
         logdet = torch.empty(B, device=dev)
         with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
             rc = eng.lib.hcf_train_forward_sr(eng.handle, hr.data_ptr(), lr.data_ptr(), noise.data_ptr(),
                                               out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(), B, H, W,
                                               module._stream(idx))
@@ -260,6 +261,7 @@ class _SRNLLStep(torch.autograd.Function):
         total = sum(n for _, n, _ in ctx.meta)
         flat = torch.empty(total, device=ctx.keep[0].device, dtype=torch.float32)
         with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
             rc = eng.lib.hcf_train_backward(eng.handle, float(g_nll), flat.data_ptr(), total,
                                             C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
         _lib.check(rc, eng.handle, "hcf_train_backward")
@@ -296,12 +298,14 @@ class _SRReverseStep(torch.autograd.Function):
                 keep.append(e)
                 arr[i] = e.data_ptr()
         with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 1), eng.handle, "hcf_train_select_tape")
             rc = eng.lib.hcf_train_inverse(eng.handle, lr.data_ptr(), arr, len(shapes), float(tau), int(seed),
                                            out.data_ptr(), B, h, w, 0 if clamp else _lib.FLAG_NO_CLAMP,
                                            module._stream(idx))
         _lib.check(rc, eng.handle, "hcf_train_inverse")
         ctx.eng, ctx.idx = eng, idx
         ctx.keep = (lr, keep)
+        ctx.lr_needs_grad = bool(lr.requires_grad)
         ctx.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
         return out
 
@@ -311,15 +315,59 @@ class _SRReverseStep(torch.autograd.Function):
         total = sum(n for _, n, _ in ctx.meta)
         g_out = g_out.to(torch.float32).contiguous()
         flat = torch.empty(total, device=g_out.device, dtype=torch.float32)
+        g_lr = torch.empty_like(ctx.keep[0]) if ctx.lr_needs_grad else None
         with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 1), eng.handle, "hcf_train_select_tape")
             rc = eng.lib.hcf_train_backward_inverse(eng.handle, g_out.data_ptr(), flat.data_ptr(), total,
+                                                    None if g_lr is None else g_lr.data_ptr(),
                                                     C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
         _lib.check(rc, eng.handle, "hcf_train_backward_inverse")
         grads, off = [], 0
         for shape, n, need in ctx.meta:
             grads.append(flat[off:off + n].view(shape) if need else None)
             off += n
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, g_lr, None, None, None, None) + tuple(grads)
+
+
+class _RescaleForwardStep(torch.autograd.Function):
+    """``fake_LR, z1, z2 = netG(hr=, reverse=False)`` of the rescaling net with gradients
+    (HCFlow_Rescaling_model.optimize_parameters, :212-216): tape slot 0 (the inverse pass of the same step uses slot 1)."""
+
+    @staticmethod
+    def forward(ctx, module, hr, clamp, *params):
+        dev = hr.device
+        eng, idx = module._engine_for(dev)
+        cfg = module.cfg
+        B, _, H, W = hr.shape
+        out_lr = torch.empty(B, 3, H // 4, W // 4, device=dev)
+        z1 = torch.empty(B, cfg.level_channels(0) - cfg.split_channels(0), H // 2, W // 2, device=dev)
+        z2 = torch.empty(B, cfg.level_channels(1) - cfg.split_channels(1), H // 4, W // 4, device=dev)
+        with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
+            rc = eng.lib.hcf_train_forward_rescale(eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(),
+                                                   B, H, W, 0 if clamp else _lib.FLAG_NO_CLAMP, module._stream(idx))
+        _lib.check(rc, eng.handle, "hcf_train_forward_rescale")
+        ctx.eng, ctx.idx, ctx.keep = eng, idx, hr
+        ctx.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
+        return out_lr, z1, z2
+
+    @staticmethod
+    def backward(ctx, g_lr, g_z1, g_z2):
+        eng, idx = ctx.eng, ctx.idx
+        total = sum(n for _, n, _ in ctx.meta)
+        gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_lr, g_z1, g_z2)]
+        flat = torch.empty(total, device=ctx.keep.device, dtype=torch.float32)
+        with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
+            rc = eng.lib.hcf_train_backward_rescale(eng.handle, *[None if g is None else g.data_ptr() for g in gs],
+                                                    flat.data_ptr(), total,
+                                                    C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+        _lib.check(rc, eng.handle, "hcf_train_backward_rescale")
+        grads, off = [], 0
+        for shape, n, need in ctx.meta:
+            grads.append(flat[off:off + n].view(shape) if need else None)
+            off += n
+        return (None, None, None) + tuple(grads)
 
 
 # ------------------------------------------------------------------ engine-backed top modules
@@ -389,8 +437,8 @@ class _EngineModule(nn.Module):
     def _check_inference(self, reverse=False):
         if self._wants_grad():
             raise NotImplementedError(
-                "hcflow_amd builds the backward passes of the SR nets (NLL objective and sampling path); gradients "
-                "through the rescaling net are not built yet (SURVEY.md section 8f). Call under torch.no_grad().")
+                "this call has no backward pass in hcflow_amd (built: SR NLL forward, SR / rescaling sampling path, "
+                "rescaling forward). Call under torch.no_grad().")
         if self.training and reverse and self._pending_actnorms():
             raise NotImplementedError(
                 "un-initialised ActNorm layers in train() mode on the REVERSE path: the reference would fit them to "
@@ -430,7 +478,7 @@ class _EngineModule(nn.Module):
         return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
     def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None):
-        if self._wants_grad() and self.cfg.sr:
+        if self._wants_grad() or (torch.is_grad_enabled() and torch.is_tensor(lr) and lr.requires_grad):
             if self.training and self._pending_actnorms():
                 raise NotImplementedError(
                     "un-initialised ActNorm layers in train() mode on the REVERSE path: run one forward (hr -> z) pass "
@@ -439,7 +487,8 @@ class _EngineModule(nn.Module):
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             tau = 0.0 if eps_std is None else float(eps_std)
-            return _SRReverseStep.apply(self, self._prep(lr, dev), tau, seed, bool(clamp), eps, *list(self.parameters()))
+            lr_t = lr.to(device=dev, dtype=torch.float32).contiguous()          # keeps the autograd link to the caller's lr
+            return _SRReverseStep.apply(self, lr_t, tau, seed, bool(clamp), eps, *list(self.parameters()))
         self._check_inference(reverse=True)
         dev = next(self.parameters()).device
         eng, idx = self._engine_for(dev)
@@ -561,6 +610,12 @@ class HCFlowNet_Rescaling(_EngineModule):
 
     def normal_flow_diracLR(self, hr, lr=None, u=None, step=None, training=True, clamp=True):
         """hr -> (clamp(LR^), z1, z2)   (HCFlowNet_Rescaling_arch.py:39-46)."""
+        if self._wants_grad():
+            dev = next(self.parameters()).device
+            if self.training and self._pending_actnorms():
+                with torch.no_grad():                       # fit the ActNorms on this batch first (ActNorms.py:78-80)
+                    self.normal_flow_diracLR(hr)
+            return _RescaleForwardStep.apply(self, self._prep(hr, dev), bool(clamp), *list(self.parameters()))
         self._check_inference()
         dev = next(self.parameters()).device
         eng, idx = self._engine_for(dev)

@@ -183,13 +183,21 @@ int launch_step_inv_bwd(const StepInvBwdArgs& a, hipStream_t st);
 int launch_mask_unit_range(View z, View g, int B, int H, int W, hipStream_t st);      // g = (0 <= z <= 1) ? g : 0
 
 struct PriorBwdArgs {
-  int B, H, W, C;          // C = channels of the latent; h has 2C (mean = h[0::2], logs = h[1::2])
+  int B, H, W, C;          // C = channels of the latent; h has 2C (mean = h[0::2], s = h[1::2])
   View a, h, ga, gh;       // ga (=), gh (=)
   float gobj;
+  int rescale;             // 0: logs = s (SR); 1: logs = 0.318 atan(2 s) (rescaling net, ConditionalFlow.py:78,90)
+  const float* gz_nchw;    // encode backward: dL/dz of z = (a - mean) e^-logs, NCHW [B,C,H,W] (nullptr: zero)
 };
 int launch_gauss_logp_bwd(const PriorBwdArgs& a, hipStream_t st);
 // a = mean + e^logs * eps (SR prior sample): gh[2c] = ga[c], gh[2c+1] = ga[c] * (a[c] - mean)   (ga in, gh out)
 int launch_gauss_sample_bwd(const PriorBwdArgs& a, hipStream_t st);
+// z = (a - mean) e^-logs (rescaling forward, ConditionalFlow.py:76-80): ga (=), gh (=) from gz_nchw
+int launch_gauss_encode_bwd(const PriorBwdArgs& a, hipStream_t st);
+// gz[pix][c] += g_nchw[b][c][pix] (masked where z is outside [0,1] when clamp01): backward of an NCHW (clamped) output
+int launch_add_nchw_grad(const float* g_nchw, View z, View gz, int B, int H, int W, int clamp01, hipStream_t st);
+// out = (0 <= raw <= 1) ? g : 0 over n floats (flat NCHW tensors)
+int launch_mask_flat(const float* g, const float* raw, float* out, size_t n, hipStream_t st);
 // d/dz of logp(lr; mean := Quant(z), logs = -6) with the straight-through Quant: gz += gobj * (lr - q(z)) * e^12
 int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, int W, float gobj, hipStream_t st);
 int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st);      // out += alpha * in

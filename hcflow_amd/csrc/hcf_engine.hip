@@ -1052,7 +1052,6 @@ struct hcf_engine {
   template <class F>
   int run_pass(F&& body, hipStream_t stream, uint32_t flags = 0) {
     pass_flags = flags;
-    tape_valid = false;          // the inference passes reuse the activation arena
     if (!finalized) return fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
@@ -1132,6 +1131,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->ovf_flag) hipFree(e->ovf_flag);
   if (e->stats_dev) hipFree(e->stats_dev);
   if (e->garena.base) hipFree(e->garena.base);
+  for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
@@ -1181,7 +1181,7 @@ int hcf_finalize(hcf_engine* e, int device) {
   hipDeviceSynchronize();      // packed weights of a previous finalize may still be in use
   e->free_weights();
   e->train_ready = false;
-  e->tape_valid = false;
+  e->invalidate_tapes();
   e->host_stale = false;
   e->device = device;
   e->spec_mode = false;
@@ -1243,7 +1243,28 @@ int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const 
 
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream) {
   if (!e || numel < 0) return HCF_ERR_ARG;
-  return e->run_backward(1, grad_nll, nullptr, dparams, (size_t)numel, (hipStream_t)stream);
+  hcf_engine::BwdIn in = {1, grad_nll, nullptr, nullptr, nullptr, nullptr};
+  return e->run_backward(in, dparams, (size_t)numel, (hipStream_t)stream);
+}
+
+int hcf_train_select_tape(hcf_engine* e, int32_t slot) {
+  if (!e || slot < 0 || slot > 1) return HCF_ERR_ARG;
+  e->cur_slot = slot;
+  return HCF_OK;
+}
+
+int hcf_train_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B,
+                              int32_t H, int32_t W, uint32_t flags, hcf_stream_t stream) {
+  if (!e || !hr || !out_lr || !out_z1 || !out_z2 || B < 1 || H < 1 || W < 1) return HCF_ERR_ARG;
+  if (H % 4 || W % 4) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by 4");
+  return e->run_train_forward_rescale(hr, out_lr, out_z1, out_z2, B, H, W, flags, (hipStream_t)stream);
+}
+
+int hcf_train_backward_rescale(hcf_engine* e, const float* g_lr, const float* g_z1, const float* g_z2, float* dparams,
+                               int64_t numel, hcf_stream_t stream) {
+  if (!e || numel < 0) return HCF_ERR_ARG;
+  hcf_engine::BwdIn in = {3, 0.f, g_lr, nullptr, g_z1, g_z2};
+  return e->run_backward(in, dparams, (size_t)numel, (hipStream_t)stream);
 }
 
 int hcf_train_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
@@ -1252,9 +1273,11 @@ int hcf_train_inverse(hcf_engine* e, const float* lr, const float* const* eps, i
   return e->run_train_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags, (hipStream_t)stream);
 }
 
-int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, hcf_stream_t stream) {
+int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, float* grad_lr,
+                               hcf_stream_t stream) {
   if (!e || numel < 0) return HCF_ERR_ARG;
-  return e->run_backward(2, 1.f, grad_out, dparams, (size_t)numel, (hipStream_t)stream);
+  hcf_engine::BwdIn in = {2, 1.f, grad_out, grad_lr, nullptr, nullptr};
+  return e->run_backward(in, dparams, (size_t)numel, (hipStream_t)stream);
 }
 
 int hcf_bind_param_device(hcf_engine* e, const char* key, const float* dev_ptr) {

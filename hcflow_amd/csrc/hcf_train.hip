@@ -285,8 +285,66 @@ __global__ __launch_bounds__(256) void gauss_sample_bwd_kernel(const PriorBwdArg
   float* gh = a.gh.p + pix * a.gh.cs + a.gh.c0;
   for (int c = 0; c < a.C; ++c) {
     gh[2 * c] = ga[c];                               // a = mean + e^logs eps
-    gh[2 * c + 1] = ga[c] * (ap[c] - hp[2 * c]);     // d a / d logs = e^logs eps = a - mean
+    float gl = ga[c] * (ap[c] - hp[2 * c]);          // d a / d logs = e^logs eps = a - mean
+    if (a.rescale) { const float s = hp[2 * c + 1]; gl *= 0.636f / (1.f + 4.f * s * s); }   // logs = 0.318 atan(2 s)
+    gh[2 * c + 1] = gl;
   }
+}
+
+// z = (a - mean) e^-logs  ->  ga = gz e^-logs, g mean = -ga, g logs = -gz z
+__global__ __launch_bounds__(256) void gauss_encode_bwd_kernel(const PriorBwdArgs a) {
+  const int hw = a.H * a.W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* ap = a.a.p + pix * a.a.cs + a.a.c0;
+  const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+  float* ga = a.ga.p + pix * a.ga.cs + a.ga.c0;
+  float* gh = a.gh.p + pix * a.gh.cs + a.gh.c0;
+  for (int c = 0; c < a.C; ++c) {
+    const float s = hp[2 * c + 1];
+    const float logs = a.rescale ? logscale_of(s) : s;
+    const float e = expf(-logs);
+    const float gz = a.gz_nchw ? a.gz_nchw[((size_t)blockIdx.y * a.C + c) * hw + i] : 0.f;
+    const float z = (ap[c] - hp[2 * c]) * e;
+    ga[c] = gz * e;
+    gh[2 * c] = -gz * e;
+    float gl = -gz * z;
+    if (a.rescale) gl *= 0.636f / (1.f + 4.f * s * s);
+    gh[2 * c + 1] = gl;
+  }
+}
+int launch_gauss_encode_bwd(const PriorBwdArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);
+  hipLaunchKernelGGL(gauss_encode_bwd_kernel, grid, dim3(256), 0, st, a);
+  HCF_RET_T();
+}
+
+__global__ __launch_bounds__(256) void add_nchw_grad_kernel(const float* g, View z, View gz, int hw, int clamp01) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  for (int c = 0; c < gz.n; ++c) {
+    const float v = z.p[pix * z.cs + z.c0 + c];
+    if (!clamp01 || (v >= 0.f && v <= 1.f)) gz.p[pix * gz.cs + gz.c0 + c] += g[((size_t)blockIdx.y * gz.n + c) * hw + i];
+  }
+}
+int launch_add_nchw_grad(const float* g_nchw, View z, View gz, int B, int H, int W, int clamp01, hipStream_t st) {
+  const dim3 grid((unsigned)step_blocks_per_sample(H, W), (unsigned)B);
+  hipLaunchKernelGGL(add_nchw_grad_kernel, grid, dim3(256), 0, st, g_nchw, z, gz, H * W, clamp01);
+  HCF_RET_T();
+}
+
+__global__ __launch_bounds__(256) void mask_flat_kernel(const float* g, const float* raw, float* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = raw[i];
+  out[i] = (v >= 0.f && v <= 1.f) ? g[i] : 0.f;
+}
+int launch_mask_flat(const float* g, const float* raw, float* out, size_t n, hipStream_t st) {
+  if (n == 0) return HCF_OK;
+  hipLaunchKernelGGL(mask_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, raw, out, n);
+  HCF_RET_T();
 }
 int launch_gauss_sample_bwd(const PriorBwdArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)step_blocks_per_sample(a.H, a.W), (unsigned)a.B);

@@ -154,7 +154,21 @@ int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t nu
  * every parameter like hcf_train_backward. */
 int hcf_train_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
                       float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
-int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, hcf_stream_t stream);
+int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dparams, int64_t numel, float* grad_lr,
+                               hcf_stream_t stream);     /* grad_lr: optional device [B,3,h,w], receives dL/d lr */
+
+/* Rescaling net (reference: one generator step of HCFlow_Rescaling_model.optimize_parameters, :212-256 --
+ * `fake_LR, z1, z2 = netG(hr, reverse=False)`; losses on all three; `fake_H = netG(lr=Quant(fake_LR), reverse=True)`;
+ * loss on fake_H; ONE backward through both passes). hcf_train_forward_rescale = hcf_forward_rescale with a tape;
+ * hcf_train_backward_rescale takes dL/d(out_lr), dL/d z1, dL/d z2 (device, each nullable; the clamp mask of out_lr is
+ * applied inside). Both passes of the step must keep their tapes alive at once: hcf_train_select_tape picks the slot
+ * (0 or 1) that the following taped passes / backward calls use. With hcf_train_backward_inverse's grad_lr the
+ * gradient flows from the inverse pass into the forward pass (through the caller's straight-through Quant). */
+int hcf_train_select_tape(hcf_engine* e, int32_t slot);
+int hcf_train_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B,
+                              int32_t H, int32_t W, uint32_t flags, hcf_stream_t stream);
+int hcf_train_backward_rescale(hcf_engine* e, const float* g_lr, const float* g_z1, const float* g_z2, float* dparams,
+                               int64_t numel, hcf_stream_t stream);
 
 /* In-place parameter updates on the GPU (optimiser steps; reference: base_model / HCFlow_SR_model keep netG's
  * parameters on the device and Adam updates them in place, HCFlow_SR_model.py:108-125,202). After hcf_finalize,

@@ -185,22 +185,25 @@ def grad_digest(g, i):
     return np.array([np.sqrt((g * g).sum()), g.sum(), (g * r).sum()])
 
 
-def check_grads_against_fixture(g, grads, rtol=2e-4):
+def check_grads_against_fixture(g, grads, rtol=2e-4, elem_rtol=None):
     """``grads``: list of per-parameter gradient arrays in state_dict order. Digest check for every tensor
     (norm, sum, random projection; errors relative to the tensor's gradient norm), element check for the small ones."""
     dig = g["gdigest"]
+    elem_rtol = rtol if elem_rtol is None else elem_rtol
     gmax = float(dig[:, 0].max())
     for i, gr in enumerate(grads):
         want = dig[i]
         have = grad_digest(gr, i)
-        scale = max(want[0], 1e-6 * gmax)
+        scale = max(want[0], 2e-5 * gmax)          # tensors with |g| << gmax carry fp32 cancellation noise ~1e-8 gmax
         n = np.asarray(gr).size
         assert abs(have[0] - want[0]) <= rtol * scale, (i, have, want)
         assert abs(have[1] - want[1]) <= rtol * scale * np.sqrt(n), (i, have, want)
         assert abs(have[2] - want[2]) <= rtol * scale * 4, (i, have, want)
         if "g_%d" % i in g.files:
             ref = g["g_%d" % i]
-            assert np.abs(np.asarray(gr, np.float64) - ref).max() <= rtol * max(np.abs(ref).max(), 1e-6 * gmax), i
+            # (relative to the tensor's own largest element, plus an fp32 noise floor relative to the largest gradient
+            #  of the net: gradients 1e-6 of gmax are sums of much larger cancelling terms)
+            assert np.abs(np.asarray(gr, np.float64) - ref).max() <= elem_rtol * max(np.abs(ref).max(), 1e-6 * gmax) + 1e-8 * gmax, i
 
 
 @pytest.mark.parametrize("name", GRADS)
