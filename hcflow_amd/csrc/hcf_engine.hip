@@ -1230,7 +1230,12 @@ int hcf_get_precision(const hcf_engine* e) { return e ? e->precision : HCF_ERR_A
 
 int64_t hcf_fallback_count(const hcf_engine* e) { return e ? e->n_fallbacks : -1; }
 
-size_t hcf_workspace_bytes(const hcf_engine* e) { return e ? e->arena.cap : 0; }
+size_t hcf_workspace_bytes(const hcf_engine* e) {      // inference arena + the training tapes' activation / gradient arenas
+  if (!e) return 0;
+  size_t n = e->arena.cap + e->garena.cap;
+  for (const auto& t : e->slots) n += t.a.cap + t.g.cap;
+  return n;
+}
 size_t hcf_weight_bytes(const hcf_engine* e) { return e ? e->weight_bytes : 0; }
 
 int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr,
