@@ -60,6 +60,9 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle 
 #ifndef HCF_DX_PIN
 #define HCF_DX_PIN 2
 #endif
+#ifndef HCF_PRESPLIT
+#define HCF_PRESPLIT 0   // 1: timing experiment only (pre-split activation format, see profiles/r01_f16x3_notes.md)
+#endif
 #ifndef HCF_ABL
 #define HCF_ABL 0     // timing ablations, build with -DHCF_ABL=bits: 1 no weight staging, 2 no activation staging, 4 no barriers
 #endif
@@ -234,7 +237,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       v.w = 0.f;                                                                                  \
     }                                                                                             \
     union { f16x4 h[2]; f32x4 f; } u_;                                                            \
-    if (HCF_ABL & 8) { /* timing only: pretend the tensor is stored pre-split (bit mask instead of the split) */ \
+    if (HCF_PRESPLIT) { /* timing experiment: the tensor already holds [16 hi | 16 lo] f16 per 16-channel chunk */ \
+      u_.f = v;                                                                                   \
+    } else if (HCF_ABL & 8) { /* timing only: pretend the tensor is stored pre-split (bit mask instead of the split) */ \
       _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
         v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[e]) & 0x33ff33ffu);        \
       u_.f = v;                                                                                   \
@@ -255,11 +260,15 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       const int q = tid + NTHR * s;                                                               \
       if (q < NLOAD) {                                                                            \
+        if (HCF_PRESPLIT) { /* one 16-byte piece straight into the record */                      \
+          *reinterpret_cast<f32x4*>(lds + (q >> 2) * REC + (q & 3) * 16) = stg[s];                 \
+        } else {                                                                                  \
         char* rec = lds + (q >> 2) * REC + (q & 3) * 8;                                           \
         union { f16x4 h[2]; f32x4 f; } u_;                                                        \
         u_.f = stg[s];                                                                            \
         *reinterpret_cast<f16x4*>(rec) = u_.h[0];                                                 \
         *reinterpret_cast<f16x4*>(rec + 32) = u_.h[1];                                            \
+        }                                                                                         \
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
