@@ -401,3 +401,27 @@ def test_rescaling_training_loop_runs_and_improves():
         assert hist[-1] < hist[0], hist
     finally:
         net.set_precision("exact")
+
+
+def test_training_api_error_paths():
+    """Misuse is reported, never silently computed: a second backward on the same graph, odd sizes (squeeze2d's
+    assert, Basic.py:136), autograd through a path that has no backward."""
+    from hcflow_amd import _lib
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(2)
+    hr = torch.rand(1, 3, 32, 32, generator=g).cuda()
+    lr = torch.rand(1, 3, 8, 8, generator=g).cuda()
+    _, nll = net(hr=hr, lr=lr, reverse=False)
+    nll.backward(retain_graph=True)
+    with pytest.raises(_lib.HcfError):                 # the engine's tape is consumed by the first backward
+        nll.backward()
+    with pytest.raises((_lib.HcfError, AssertionError)):
+        net(hr=torch.rand(1, 3, 30, 32).cuda(), lr=lr, reverse=False)
+    # a taped forward whose backward never runs must not poison later passes
+    _, nll2 = net(hr=hr, lr=lr, reverse=False)
+    with torch.no_grad():
+        out = net(lr=lr, eps_std=0.5, reverse=True)
+    assert bool(torch.isfinite(out).all())
+    nll2.backward()                                    # inference in between used its own arena: the tape is intact
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
