@@ -222,7 +222,8 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
   if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1 || !a0.part)
     return HCF_ERR_ARG;
   WgradArgs a = a0;
-  a.dbg = getenv("HCF_WG_DBG") ? atoi(getenv("HCF_WG_DBG")) : 0;
+  static const int wg_dbg = getenv("HCF_WG_DBG") ? atoi(getenv("HCF_WG_DBG")) : 0;   // read once
+  a.dbg = wg_dbg;
   int nicb = 0, cin = 0;
   for (int i = 0; i < a.nsrc; ++i) {
     if ((a.H >> a.src[i].up) << a.src[i].up != a.H || (a.W >> a.src[i].up) << a.src[i].up != a.W) return HCF_ERR_ARG;

@@ -553,7 +553,8 @@ struct hcf_engine {
 
   // f16x3 mode can run FCN conv1 (3x3 -> 64) and conv2 (1x1 64 -> 64) as ONE launch
   bool can_fuse_fcn(const Conv& c1, const Conv& c2) const {
-    if (getenv("HCF_NO_FUSE_FCN")) return false;      // debugging aid
+    static const bool off = getenv("HCF_NO_FUSE_FCN") != nullptr;      // debugging aid, read once
+    if (off) return false;
     if (taping) return false;                         // the backward pass needs the intermediate tensor
     return use_f16 && c1.wpack16 && c2.wpack16 && c1.taps == 9 && c2.taps == 1 && c1.cout == 64 && c2.cout == 64 &&
            c2.nsrc == 1 && c2.src_n[0] == 64;
@@ -724,7 +725,8 @@ struct hcf_engine {
   // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
   // f16x3 mode: the last conv of an FCN coupling net can finish the inverse flow step in its epilogue
   bool can_fuse_tail(const Step& s) const {
-    if (getenv("HCF_NO_FUSE_TAIL")) return false;     // debugging aid
+    static const bool off = getenv("HCF_NO_FUSE_TAIL") != nullptr;     // debugging aid, read once
+    if (off) return false;
     if (taping) return false;
     const Conv& c = s.c[2];
     return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= 24;   // the 48-channel variant spills
