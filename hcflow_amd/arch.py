@@ -418,6 +418,14 @@ class _EngineModule(nn.Module):
                 # same tensors, new contents (optimiser step): rewrite the packs on the device
                 with torch.cuda.device(idx):
                     eng.refresh_from_device(self._stream(idx))
+            elif on_dev and ent.get("ptrs") is not None:
+                # other tensors of the same shapes (nn.DataParallel replicas are re-created every forward,
+                # HCFlow_SR_model.py:33-36 in the non-distributed case): re-bind and refresh on the device
+                with torch.cuda.device(idx):
+                    for key, p in named:
+                        eng.bind_param_device(key, p.data_ptr())
+                    eng.refresh_from_device(self._stream(idx))
+                ent["ptrs"] = ptrs
             else:
                 sd = self.state_dict()
                 for key, t in sd.items():

@@ -320,3 +320,32 @@ def test_full_size_div2k_validation_image_ragged_shape():
             net.set_precision("exact")
     assert maxdiff(fa, ex) <= 1e-4 * max(1.0, float(ex.abs().max()))
     assert torch.equal(d0, d1) and float(d0.min()) >= 0.0 and float(d0.max()) <= 1.0
+
+
+def test_rebinding_to_new_parameter_tensors_refreshes_on_device():
+    """Parameters replaced by NEW tensors of the same shapes (what nn.DataParallel's replicate does every forward, or
+    ``p.data = other``): the engine re-binds and repacks on the device; results equal a freshly built module."""
+    from hcflow_amd import HCFlowNet_SR
+    cfg = preset("SR_4X_tiny")
+    pa, pb = cached_params("SR_4X_tiny", 11), cached_params("SR_4X_tiny", 12)
+    net = build_net(cfg, pa)
+    g = torch.Generator().manual_seed(4)
+    lr = torch.rand(2, 3, 24, 24, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.6 for s in eps_shapes(cfg, 2, 24, 24)]
+    with torch.no_grad():
+        net.reverse_flow_diracLR(lr, None, None, eps_std=0.6, eps=eps, clamp=False)       # host path, binds pointers
+        for k, p in net.named_parameters():
+            p.data = pb[k].to("cuda:0").clone()                                            # new tensors, new values
+        got = net.reverse_flow_diracLR(lr, None, None, eps_std=0.6, eps=eps, clamp=False)
+    assert net._engines[0]["ptrs"] is not None
+    ref = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    ref.load_state_dict(pb, strict=True)
+    for m in ref.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    with torch.no_grad():
+        want = ref.to("cuda:0").eval().reverse_flow_diracLR(lr, None, None, eps_std=0.6, eps=eps, clamp=False)
+    assert maxdiff(got, want) <= 2e-5 * max(1.0, float(want.abs().max()))
+    with torch.no_grad():                                   # leave the cached module as other tests expect it
+        for k, p in net.named_parameters():
+            p.data = pa[k].to("cuda:0").clone()
