@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Probe: does running two half-batches concurrently (two engines, two HIP streams, two host threads) beat one
+full-batch pass? Kernels of the two streams can fill each other's tail waves and barrier stalls.
+    python tools/two_stream_probe.py [--batch 16] [--steps 8]"""
+import argparse
+import contextlib
+import os
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from hcflow_amd import HCFlowNet_SR, preset, make_params  # noqa: E402
+
+
+def build(cfg, params):
+    with contextlib.redirect_stdout(sys.stderr):
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(params, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    return net.cuda().eval().set_precision("f16x3")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--ways", type=int, default=2)
+    args = ap.parse_args()
+    cfg = preset("SR_DF2K_4X")
+    params = make_params(cfg, 1234)
+    nets = [build(cfg, params) for _ in range(args.ways)]
+    B = args.batch
+    lr = torch.rand(B, 3, 160, 160).cuda()
+    with torch.no_grad():
+        for n in nets:
+            n(lr=lr[:B // args.ways], eps_std=0.8, reverse=True)
+        nets[0](lr=lr, eps_std=0.8, reverse=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nets[0](lr=lr, eps_std=0.8, reverse=True)
+        torch.cuda.synchronize()
+        one = (time.perf_counter() - t0) / args.steps
+        streams = [torch.cuda.Stream() for _ in range(args.ways)]
+        parts = lr.chunk(args.ways)
+
+        def work(i):
+            with torch.no_grad(), torch.cuda.stream(streams[i]):
+                for _ in range(args.steps):
+                    nets[i](lr=parts[i], eps_std=0.8, reverse=True)
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(args.ways)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        two = (time.perf_counter() - t0) / args.steps
+    print("one stream, B=%d: %.1f ms/step = %.1f img/s;  %d streams x B=%d: %.1f ms/step = %.1f img/s  (%+.1f %%)" % (
+        B, 1e3 * one, B / one, args.ways, B // args.ways, 1e3 * two, B / two, 100 * (one / two - 1)))
+
+
+if __name__ == "__main__":
+    main()
