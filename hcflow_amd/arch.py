@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -384,7 +385,10 @@ class _EngineModule(nn.Module):
         assert have == spec, "internal: module tree does not match the reference state_dict table"
         # engines are per device (nn.DataParallel replicas share this dict but not the entries)
         object.__setattr__(self, "_engines", {})
-        object.__setattr__(self, "_precision", ["exact"])
+        # conv numerics: "exact" unless HCFLOW_PRECISION=f16x3 is set (lets the unmodified reference scripts opt in)
+        default_prec = os.environ.get("HCFLOW_PRECISION", "exact")
+        assert default_prec in _lib.Engine.PRECISIONS, "HCFLOW_PRECISION must be one of %s" % list(_lib.Engine.PRECISIONS)
+        object.__setattr__(self, "_precision", [default_prec])
 
     def set_precision(self, mode: str):
         """"exact": fp32 MFMA convolutions (default). "f16x3": fp32-equivalent split products on the
