@@ -57,6 +57,13 @@ __device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, co
 // scalar loads into SGPRs, which then feed the FMAs directly. Left to itself the compiler reads them with 16+
 // uniform-address vector loads per pixel once the kernel also stores to global memory (it can no longer prove
 // the table invariant).
+#ifndef HCF_TAIL_VECTOR_TABLES
+#define HCF_TAIL_VECTOR_TABLES 0   // 1 / 2: reproduce the round-1 fault (tables through per-lane vector loads; 2 adds a full wait)
+#endif
+#if HCF_TAIL_VECTOR_TABLES
+typedef const float* step_cptr;
+__device__ __forceinline__ step_cptr const_table(const float* p) { return p; }
+#else
 typedef const float __attribute__((address_space(4)))* step_cptr;
 __device__ __forceinline__ step_cptr const_table(const float* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -64,10 +71,27 @@ __device__ __forceinline__ step_cptr const_table(const float* p) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return (step_cptr)(((uint64_t)hi << 32) | lo);
 }
+#endif
 
 // y = M z with M row-major [CMAX][CMAX] (host pads rows/cols beyond C with zeros)
 template <int CMAX>
 __device__ __forceinline__ void matvec(step_cptr M, const float (&z)[CMAX], float (&y)[CMAX]) {
+#if HCF_TAIL_VECTOR_TABLES == 2
+  if (CMAX <= 12) {                          // experiment: every table load has landed before the first use
+    float m[CMAX * CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX * CMAX; ++i) m[i] = M[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < CMAX; ++k) acc = fmaf(m[c * CMAX + k], z[k], acc);
+      y[c] = acc;
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) {
     float acc = 0.f;
