@@ -1,0 +1,130 @@
+"""-m gpu: seeded fuzzing of the hot-path entry points against fp64 PyTorch evaluations / the oracle: random conv
+configurations (1-3 source windows, nearest-upsampled sources, residual epilogues, activations, ragged sizes, channel
+tails), random conv-backward shapes, and random network configurations (steps per level, steps after the split, RRDB
+counts)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hcflow_oracle as O
+from hcflow_amd.config import preset, eps_shapes
+from hcflow_amd.params import make_params
+
+pytestmark = pytest.mark.gpu
+
+ACTS = [None, "relu", "lrelu"]
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double()).abs().max() / max(1e-30, float(b.double().abs().max())))
+
+
+def _conv_case(rng):
+    n_src = int(rng.integers(1, 4))
+    ups = [0] + [int(rng.integers(1, 3)) if rng.random() < 0.3 else 0 for _ in range(n_src - 1)]
+    m = 1 << max(ups)
+    H = max(1, int(rng.integers(1, 12))) * m
+    W = max(1, int(rng.integers(1, 24))) * m
+    cs = [int(rng.choice([1, 3, 6, 10, 21, 32, 64, 96, 128])) for _ in range(n_src)]
+    cout = int(rng.choice([3, 6, 12, 22, 32, 48, 64, 96]))
+    k = 3 if rng.random() < 0.85 else 1
+    return dict(B=int(rng.integers(1, 4)), H=H, W=W, cs=cs, ups=ups, cout=cout, k=k, act=ACTS[int(rng.integers(0, 3))],
+                res=int(rng.integers(0, 3)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+def test_conv2d_fuzz(seed, precision):
+    from hcflow_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    c = _conv_case(rng)
+    g = torch.Generator().manual_seed(seed)
+    B, H, W, k, cout = c["B"], c["H"], c["W"], c["k"], c["cout"]
+    srcs = [torch.randn(B, n, H >> u, W >> u, generator=g) for n, u in zip(c["cs"], c["ups"])]
+    cin = sum(c["cs"])
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.2
+    scale = torch.exp(torch.randn(cout, generator=g) * 0.2)
+    act = c["act"] if c["res"] == 0 else None            # the nets never combine an activation with a residual
+    r1 = torch.randn(B, cout, H, W, generator=g) if c["res"] >= 1 else None
+    r2 = torch.randn(B, cout, H, W, generator=g) if c["res"] >= 2 else None
+    x = torch.cat([F.interpolate(s, scale_factor=2 ** u, mode="nearest") if u else s for s, u in zip(srcs, c["ups"])], 1)
+    ref = (F.conv2d(x.double(), w.double(), None, 1, k // 2) + bias.double().view(1, -1, 1, 1)) * scale.double().view(1, -1, 1, 1)
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    if r1 is not None:
+        ref = ref * 0.2 + r1.double()
+    if r2 is not None:
+        ref = ref * 0.3 + r2.double()
+    ops.set_precision(precision)
+    try:
+        out = ops.conv2d([s.cuda() for s in srcs], w, bias, scale, act, c["ups"], res1=None if r1 is None else r1.cuda(),
+                         rs1=0.2, res2=None if r2 is None else r2.cuda(), rs2=0.3)
+    finally:
+        ops.set_precision("exact")
+    assert _rel(out, ref) <= 4e-6, (c, _rel(out, ref))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_conv2d_backward_fuzz(seed):
+    from hcflow_amd import ops
+    rng = np.random.default_rng(2000 + seed)
+    c = _conv_case(rng)
+    c["cout"] = min(c["cout"], 64)
+    g = torch.Generator().manual_seed(100 + seed)
+    B, H, W, k, cout = c["B"], c["H"], c["W"], c["k"], c["cout"]
+    srcs = [torch.randn(B, n, H >> u, W >> u, generator=g) for n, u in zip(c["cs"], c["ups"])]
+    cin = sum(c["cs"])
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    gy = torch.randn(B, cout, H, W, generator=g)
+    s64 = [s.double().requires_grad_(True) for s in srcs]
+    w64 = w.double().requires_grad_(True)
+    x = torch.cat([F.interpolate(s, scale_factor=2 ** u, mode="nearest") if u else s for s, u in zip(s64, c["ups"])], 1)
+    F.conv2d(x, w64, None, 1, k // 2).backward(gy.double())
+    dsrcs, dw, db = ops.conv2d_backward([s.cuda() for s in srcs], w, gy.cuda(), c["ups"])
+    for d, s in zip(dsrcs, s64):
+        assert _rel(d, s.grad) <= 4e-6, (c, _rel(d, s.grad))
+    assert _rel(dw, w64.grad) <= 4e-6, (c, _rel(dw, w64.grad))
+    assert _rel(db, gy.double().sum(dim=(0, 2, 3))) <= 2e-6
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_network_configurations_match_oracle(seed):
+    """Depth / split variations of the SR nets (K steps per level, how many of them act on the split half, RRDB
+    counts): the engine builds its layer plan from the same options as the reference constructor; inverse and NLL
+    forward against the oracle on the same seeded weights."""
+    from hcflow_amd import HCFlowNet_SR
+    rng = np.random.default_rng(3000 + seed)
+    base = preset("SR_4X_tiny" if seed % 2 == 0 else "SR_8X_tiny")
+    L = base.L
+    K = [int(rng.integers(1, 5)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 3)), int(rng.integers(1, 3))))
+    cfg.validate()
+    p = make_params(cfg, 500 + seed)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval()
+    g = torch.Generator().manual_seed(seed)
+    h, w = int(rng.integers(2, 6)) * 2, int(rng.integers(2, 7)) * 2
+    lr = torch.rand(2, 3, h, w, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.7 for s in eps_shapes(cfg, 2, h, w)]
+    hr = torch.rand(2, 3, h * cfg.scale, w * cfg.scale, generator=g)
+    noise = torch.rand(hr.shape, generator=g)
+    want = O.sr_inverse(lr, p, cfg, 0.7, eps=eps, clamp=False)
+    lr_o, nll_o = O.sr_forward(hr, lr, p, cfg, noise=noise)
+    with torch.no_grad():
+        got = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.7, eps=[e.cuda() for e in eps], clamp=False)
+        lr_g, nll_g = net(hr=hr.cuda(), lr=lr.cuda(), reverse=False, noise=noise.cuda())
+    sc = max(1.0, float(want.abs().max()))
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * sc, (K, after, float((got.cpu() - want).abs().max()))
+    assert float((lr_g.cpu() - lr_o).abs().max()) <= 1e-4
+    assert abs(float(nll_g) - float(nll_o)) <= 2e-4 * max(1.0, abs(float(nll_o)) / 100)
