@@ -128,3 +128,53 @@ def test_random_network_configurations_match_oracle(seed):
     assert float((got.cpu() - want).abs().max()) <= 1e-4 * sc, (K, after, float((got.cpu() - want).abs().max()))
     assert float((lr_g.cpu() - lr_o).abs().max()) <= 1e-4
     assert abs(float(nll_g) - float(nll_o)) <= 2e-4 * max(1.0, abs(float(nll_o)) / 100)
+
+
+def _grad_cmp(net, q, cfg, rtol):
+    from hcflow_amd.config import param_spec
+    sd = dict(net.named_parameters())
+    refs = {k: q[k].grad for k, _, _ in param_spec(cfg) if torch.is_tensor(q[k]) and q[k].grad is not None}
+    gmax = max(float(v.norm()) for v in refs.values())
+    worst = 0.0
+    for k, ref in refs.items():
+        have = sd[k].grad.cpu() if sd[k].grad is not None else torch.zeros_like(ref)
+        worst = max(worst, float((have - ref).norm()) / max(float(ref.norm()), 2e-5 * gmax))
+    assert worst <= rtol, worst
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_network_gradients_match_oracle_autograd(seed):
+    """NLL-step and reverse-path gradients of randomly configured SR nets (steps per level, steps after the split,
+    RRDB counts, ragged sizes) against autograd through the oracle."""
+    from hcflow_amd import HCFlowNet_SR
+    rng = np.random.default_rng(4000 + seed)
+    base = preset("SR_4X_tiny" if seed % 2 == 0 else "SR_8X_tiny")
+    K = [int(rng.integers(1, 4)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 2)), int(rng.integers(1, 3))))
+    cfg.validate()
+    p = make_params(cfg, 700 + seed)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").train()
+    g = torch.Generator().manual_seed(seed)
+    h, w = int(rng.integers(2, 5)) * 2, int(rng.integers(2, 6)) * 2
+    lr = torch.rand(2, 3, h, w, generator=g)
+    hr = torch.rand(2, 3, h * cfg.scale, w * cfg.scale, generator=g) * 0.6 + 0.2
+    noise = torch.rand(hr.shape, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.5 for s in eps_shapes(cfg, 2, h, w)]
+    # NLL step
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    O.sr_forward(hr, lr, q, cfg, noise=noise)[1].backward()
+    net.zero_grad()
+    net(hr=hr.cuda(), lr=lr.cuda(), reverse=False, noise=noise.cuda())[1].backward()
+    _grad_cmp(net, q, cfg, 5e-4)
+    # reverse path with an L1 pixel loss
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    F.l1_loss(O.sr_inverse(lr, q, cfg, 0.5, eps=eps), hr).backward()
+    net.zero_grad()
+    F.l1_loss(net(lr=lr.cuda(), eps_std=0.5, reverse=True, eps=[e.cuda() for e in eps]), hr.cuda()).backward()
+    _grad_cmp(net, q, cfg, 5e-3)          # L1's sign() and the clamp mask make single-pixel flips visible
