@@ -178,3 +178,36 @@ def test_random_network_gradients_match_oracle_autograd(seed):
     net.zero_grad()
     F.l1_loss(net(lr=lr.cuda(), eps_std=0.5, reverse=True, eps=[e.cuda() for e in eps]), hr.cuda()).backward()
     _grad_cmp(net, q, cfg, 5e-3)          # L1's sign() and the clamp mask make single-pixel flips visible
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_rescaling_configurations_match_oracle(seed):
+    """Rescaling net variations (steps per level / after the split, RRDB counts): forward and inverse vs the oracle."""
+    from hcflow_amd import HCFlowNet_Rescaling
+    rng = np.random.default_rng(5000 + seed)
+    base = preset("Rescaling_4X_tiny")
+    K = [int(rng.integers(1, 5)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 3)), int(rng.integers(1, 3))))
+    cfg.validate()
+    p = make_params(cfg, 900 + seed)
+    net = HCFlowNet_Rescaling(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval()
+    g = torch.Generator().manual_seed(seed)
+    h, w = int(rng.integers(2, 6)) * 2, int(rng.integers(2, 7)) * 2
+    hr = torch.rand(2, 3, h * 4, w * 4, generator=g)
+    lr = torch.rand(2, 3, h, w, generator=g)
+    eps = [torch.randn(s, generator=g) for s in eps_shapes(cfg, 2, h, w)]
+    lo, z1o, z2o = O.rescale_forward(hr, p, cfg)
+    inv_o = O.rescale_inverse(lr, p, cfg, 1.0, eps=eps, clamp=False)
+    with torch.no_grad():
+        lg, z1g, z2g = net(hr=hr.cuda(), reverse=False)
+        inv_g = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=1.0, eps=[e.cuda() for e in eps], clamp=False)
+    assert float((lg.cpu() - lo).abs().max()) <= 1e-4
+    assert float((z1g.cpu() - z1o).abs().max()) <= 1e-4 * max(1.0, float(z1o.abs().max()))
+    assert float((z2g.cpu() - z2o).abs().max()) <= 1e-4 * max(1.0, float(z2o.abs().max()))
+    assert float((inv_g.cpu() - inv_o).abs().max()) <= 1e-4 * max(1.0, float(inv_o.abs().max()))
