@@ -60,6 +60,9 @@ struct ConvArgs {
   const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
   const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
+  // f16x3 kernel, set by the launcher: first-round blocks (blockIdx < stagger_blocks) sleep (workgroup slot on the CU
+  // % stagger_mod) * stagger x 1024 cycles, so that the co-resident blocks run out of phase (0 = off)
+  int stagger, stagger_blocks, stagger_mod;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };

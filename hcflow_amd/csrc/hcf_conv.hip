@@ -207,26 +207,47 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue --------------------------------------------------------------------------------
+  // Residual reads go out RB at a time before the first is consumed (see hcf_conv_f16x3.hip: one s_waitcnt per value
+  // serialised 32 NT memory latencies per residual); out-of-tile lanes read a clamped address and never store.
   const int cout = a.out.n;
+  const bool has1 = a.res1.p != nullptr, has2 = a.res2.p != nullptr;
+  constexpr int RB = 8;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int oc = n * 32 + li;
     const bool ocok = oc < cout;
+    const int occ = ocok ? oc : 0;
     const float bias = a.bias[oc], scale = a.scale[oc];     // arrays are padded to NPAD
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int y = y0 + 2 * wave + m;
+      const int yc = y < H ? y : H - 1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (ocok && y < H && x < W) {
-          const size_t pix = (size_t)((size_t)b * H + y) * W + x;
-          float v = (acc[m][n][r] + bias) * scale;
-          if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
-          if (a.res1.p) v = v * a.rs1 + a.res1.p[pix * a.res1.cs + a.res1.c0 + oc];
-          if (a.res2.p) v = v * a.rs2 + a.res2.p[pix * a.res2.cs + a.res2.c0 + oc];
-          a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
+      for (int rb = 0; rb < 16; rb += RB) {
+        float r1[RB], r2[RB];
+        if (has1 || has2) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int r = rb + q;
+            const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const size_t pixc = (size_t)((size_t)b * H + yc) * W + (x < W ? x : W - 1);
+            r1[q] = has1 ? a.res1.p[pixc * a.res1.cs + a.res1.c0 + occ] : 0.f;
+            r2[q] = has2 ? a.res2.p[pixc * a.res2.cs + a.res2.c0 + occ] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int r = rb + q;
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (ocok && y < H && x < W) {
+            const size_t pix = (size_t)((size_t)b * H + y) * W + x;
+            float v = (acc[m][n][r] + bias) * scale;
+            if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+            if (has1) v = v * a.rs1 + r1[q];
+            if (has2) v = v * a.rs2 + r2[q];
+            a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
+          }
         }
       }
     }

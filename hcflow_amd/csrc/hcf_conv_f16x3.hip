@@ -60,6 +60,9 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle 
 #ifndef HCF_DX_PIN
 #define HCF_DX_PIN 2
 #endif
+#ifndef HCF_SPLIT_PER_TAP
+#define HCF_SPLIT_PER_TAP 2   // staged slots split per tap in the MFMA shadow of the last taps
+#endif
 #ifndef HCF_PRESPLIT
 #define HCF_PRESPLIT 0   // 1: timing experiment only (pre-split activation format, see profiles/r01_f16x3_notes.md)
 #endif
@@ -132,6 +135,14 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
+  if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks) {
+    // HW_REG_HW_ID (id 4) bits 19:16 = TG_ID, the workgroup's slot on its CU: the first round of blocks starts in
+    // lock-step, and since every block takes the same time they would stay in phase (all in their prologue /
+    // epilogue together, the MFMA pipe idle) for the whole launch
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+    const int n = (int)(tg % (unsigned)a.stagger_mod) * a.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
   const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -379,11 +390,13 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       }
       // the split of the NEXT chunk's staged slots rides in the MFMA shadow of the last taps (its loads were
       // issued a whole chunk of MFMAs earlier); two slots per tap
-      if (INTERLEAVE && more && !(HCF_ABL & 2) && t >= TAPS - (NSLOT + 1) / 2) {
-        constexpr int dummy = 0; (void)dummy;
-        const int s0 = 2 * (t - (TAPS - (NSLOT + 1) / 2));
-        if (s0 < NSLOT) HCF_SPLIT_SLOT(s0)
-        if (s0 + 1 < NSLOT) HCF_SPLIT_SLOT(s0 + 1)
+      constexpr int SPLIT_T0 = TAPS - (NSLOT + HCF_SPLIT_PER_TAP - 1) / HCF_SPLIT_PER_TAP;
+      if (INTERLEAVE && more && !(HCF_ABL & 2) && t >= SPLIT_T0) {
+#pragma unroll
+        for (int q = 0; q < HCF_SPLIT_PER_TAP; ++q) {
+          const int sq = HCF_SPLIT_PER_TAP * (t - SPLIT_T0) + q;
+          if (sq < NSLOT) HCF_SPLIT_SLOT(sq)
+        }
       }
       // term-major order: consecutive MFMAs hit different accumulators (MT independent chains)
 #pragma unroll
@@ -511,20 +524,43 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
   const int act = FUSE2 ? a.act2 : a.act;
+  // Residual reads are issued RB at a time (per lane and residual) before the first one is used: inside the
+  // bounds-checked store loop each load sat behind its own s_waitcnt, i.e. 64 serialised L2/HBM latencies per
+  // residual (RDB conv5: +8 % with one residual, +40 % with the RRDB skip as well). Out-of-tile lanes read a
+  // clamped (valid) address and never store.
+  const bool has1 = a.res1.p != nullptr, has2 = a.res2.p != nullptr;
+  constexpr int RB = 8;                              // residual values in flight per lane and residual
+  const int occ = ocok ? oc : 0;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int y = y0 + MT * wm + m;
+    const int yc = y < H ? y : H - 1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (ocok && y < H && x < W) {
-        const size_t pix = (size_t)((size_t)b * H + y) * W + x;
-        float v = (acc[m][r] * UNSPLIT + bias) * scale;
-        if (act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
-        if (a.res1.p) v = v * a.rs1 + a.res1.p[pix * a.res1.cs + a.res1.c0 + oc];
-        if (a.res2.p) v = v * a.rs2 + a.res2.p[pix * a.res2.cs + a.res2.c0 + oc];
-        a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
+    for (int rb = 0; rb < 16; rb += RB) {
+      float r1[RB], r2[RB];
+      if (has1 || has2) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const int r = rb + q;
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const size_t pixc = (size_t)((size_t)b * H + yc) * W + (x < W ? x : W - 1);
+          r1[q] = has1 ? a.res1.p[pixc * a.res1.cs + a.res1.c0 + occ] : 0.f;
+          r2[q] = has2 ? a.res2.p[pixc * a.res2.cs + a.res2.c0 + occ] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int r = rb + q;
+        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (ocok && y < H && x < W) {
+          const size_t pix = (size_t)((size_t)b * H + y) * W + x;
+          float v = (acc[m][r] * UNSPLIT + bias) * scale;
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          if (has1) v = v * a.rs1 + r1[q];
+          if (has2) v = v * a.rs2 + r2[q];
+          a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
+        }
       }
     }
   }
@@ -543,6 +579,12 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
+  {
+    const int per_cu = tall ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2);     // resident blocks per CU (__launch_bounds__)
+    b.stagger = (g_f16x3_ablation >> 8) & 0xff;                               // tools/conv_bench.py --ablate (n << 8)
+    b.stagger_mod = per_cu;
+    b.stagger_blocks = 256 * per_cu;
+  }
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
     if (a.src[i].up) b.any_up = 1;
