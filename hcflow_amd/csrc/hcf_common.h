@@ -63,6 +63,7 @@ struct ConvArgs {
   // f16x3 kernel, set by the launcher: first-round blocks (blockIdx < stagger_blocks) sleep (workgroup slot on the CU
   // % stagger_mod) * stagger x 1024 cycles, so that the co-resident blocks run out of phase (0 = off)
   int stagger, stagger_blocks, stagger_mod;
+  int vec_epi;             // f16x3 kernel, set by the launcher: out / residual views allow 16-byte accesses -> LDS-transposed epilogue
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -73,6 +74,10 @@ int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
 // experimental wave-specialised variant (hcf_conv_f16x3_ws.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
 int launch_conv_f16x3_ws(const ConvArgs& a, hipStream_t st);
+// split16-source variant staged by LDS-DMA (hcf_conv_f16x3_dma.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
+int launch_conv_f16x3_dma(const ConvArgs& a, hipStream_t st);
+int launch_to_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);
+int launch_max_abs_diff(const float* a, const float* b, size_t n, unsigned* out_bits, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------
 // dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   constexpr int HCS = (NTB == 1) ? 33 : 49;                      // odd row stride of the h tile (floats): conflict-free
   constexpr int T_BYTES = TAILC ? (TH * TW) * HCS * 4 : 0;
   constexpr int LDS_MAIN = A_BYTES + B_BYTES;
-  constexpr int LDS_BYTES = (LDS_MAIN > F2_BYTES ? (LDS_MAIN > T_BYTES ? LDS_MAIN : T_BYTES) : (F2_BYTES > T_BYTES ? F2_BYTES : T_BYTES));
+  constexpr int E_BYTES = (TH == 8 && TAILC == 0) ? TH * TW * NPAD * 4 : 0;     // fp32 output tile, transposed for 16-byte stores
+  constexpr int LDS_M1 = (LDS_MAIN > F2_BYTES ? (LDS_MAIN > T_BYTES ? LDS_MAIN : T_BYTES) : (F2_BYTES > T_BYTES ? F2_BYTES : T_BYTES));
+  constexpr int LDS_BYTES = LDS_M1 > E_BYTES ? LDS_M1 : E_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   char* const ldsB = lds + A_BYTES;
 
@@ -524,6 +526,43 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
   const int act = FUSE2 ? a.act2 : a.act;
+  if constexpr (TH == 8) {
+    if (a.vec_epi) {
+      // The tile goes through LDS (pixel-major fp32) so that every lane loads its residuals and stores its outputs as
+      // 16 contiguous bytes: 64 scalar dword stores per lane cost ~12 us per block on the 64-channel tile (measured in
+      // hcf_conv_f16x3_dma.hip), the transposed form half of that, and the residual reads become coalesced float4s.
+      float* const ldsT = reinterpret_cast<float*>(lds);
+      __syncthreads();                               // every wave is done with the staging buffers
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v = (acc[m][r] * UNSPLIT + bias) * scale;
+          if (act == ACT_RELU) v = fmaxf(v, 0.f);
+          else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          ldsT[px * NPAD + oc] = v;
+        }
+      __syncthreads();
+      constexpr int C4 = NPAD / 4;
+      const int n4 = a.out.n >> 2;
+      const bool h1 = a.res1.p != nullptr, h2 = a.res2.p != nullptr;
+#pragma unroll
+      for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
+        const int idx = tid + NTHR * k;
+        const int px = idx / C4, c4 = idx - px * C4;
+        const int y = y0 + (px >> 5), x = x0 + (px & 31);
+        f32x4 v = *reinterpret_cast<const f32x4*>(ldsT + px * NPAD + 4 * c4);
+        if (y < H && x < W && c4 < n4) {
+          const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
+          if (h1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
+          if (h2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
+          *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
+        }
+      }
+      return;
+    }
+  }
   // Residual reads are issued RB at a time (per lane and residual) before the first one is used: inside the
   // bounds-checked store loop each load sat behind its own s_waitcnt, i.e. 64 serialised L2/HBM latencies per
   // residual (RDB conv5: +8 % with one residual, +40 % with the RRDB skip as well). Out-of-tile lanes read a
@@ -584,6 +623,11 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     b.stagger = (g_f16x3_ablation >> 8) & 0xff;                               // tools/conv_bench.py --ablate (n << 8)
     b.stagger_mod = per_cu;
     b.stagger_blocks = 256 * per_cu;
+  }
+  {
+    auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
+    b.vec_epi = !tall && !(a.tC > 0) && a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2) &&
+                !(g_f16x3_ablation & 64);                                      // --ablate 64: scalar epilogue
   }
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
