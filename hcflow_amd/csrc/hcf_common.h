@@ -26,11 +26,13 @@ struct View {
   int c0;     // first channel of the window
   int n;      // channels in the window
   int up;     // log2 nearest-upsample factor when read as a conv source (0 = none)
+  int fmt;    // 0: fp32; 1: split16 (hcf_conv_f16x3_dma.hip: each aligned 16-channel group = [16 hi | 16 lo] f16, same bytes)
 };
 
 static inline View mkview(float* p, int cs, int c0, int n, int up = 0) {
-  View v; v.p = p; v.cs = cs; v.c0 = c0; v.n = n; v.up = up; return v;
+  View v; v.p = p; v.cs = cs; v.c0 = c0; v.n = n; v.up = up; v.fmt = 0; return v;
 }
+static inline View as_split16(View v) { v.fmt = 1; return v; }
 
 constexpr int kMaxSrc = 3;
 
@@ -67,6 +69,11 @@ struct ConvArgs {
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+// Branch-free activation for unrolled epilogues: a runtime `if (act == ...)` chain per accumulator compiles to a chain of
+// scalar branches PER VALUE (~6 us of a 64-channel tile's epilogue). act(v) = max(v, 0) + slope * min(v, 0) is exact
+// for all three cases (one of the two terms is always zero).
+__device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : act == ACT_LRELU ? 0.2f : 1.f; }
+__device__ __forceinline__ float apply_act(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
 enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
@@ -77,6 +84,7 @@ int launch_conv_f16x3_ws(const ConvArgs& a, hipStream_t st);
 // split16-source variant staged by LDS-DMA (hcf_conv_f16x3_dma.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
 int launch_conv_f16x3_dma(const ConvArgs& a, hipStream_t st);
 int launch_to_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);
+int launch_from_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);
 int launch_max_abs_diff(const float* a, const float* b, size_t n, unsigned* out_bits, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int cout = a.out.n;
   const bool has1 = a.res1.p != nullptr, has2 = a.res2.p != nullptr;
   constexpr int RB = 8;
+  const float slope = act_slope(a.act);
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int oc = n * 32 + li;
@@ -242,8 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
           if (ocok && y < H && x < W) {
             const size_t pix = (size_t)((size_t)b * H + y) * W + x;
             float v = (acc[m][n][r] + bias) * scale;
-            if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-            else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+            v = apply_act(v, slope);
             if (has1) v = v * a.rs1 + r1[q];
             if (has2) v = v * a.rs2 + r2[q];
             a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;

@@ -304,6 +304,8 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   HCF_STAGE_SPLIT();
   HCF_STAGE_WRITE();
   __syncthreads();
+  const bool dbg_on = a.dbg && (blockIdx.x & 1023) == 512 && tid == 0;     // a few mid-grid blocks
+  const unsigned long long dbg_r1 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   const int nchunk = a.nchunk;
   for (int c = 0; c < nchunk; ++c) {
@@ -425,10 +427,16 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #undef HCF_STAGE_SPLIT
 #undef HCF_STAGE_WRITE
 
-  if (a.dbg && (blockIdx.x & 1023) == 512 && tid == 0) {   // a few mid-grid blocks: shader clock vs 100 MHz reference
+  unsigned long long dbg_r2 = 0ull;
+  if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], samples at [5]
+    dbg_r2 = __builtin_amdgcn_s_memrealtime();
     atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
-    atomicAdd(a.dbg + 1, __builtin_amdgcn_s_memrealtime() - dbg_r0);
+    atomicAdd(a.dbg + 1, dbg_r2 - dbg_r0);
+    atomicAdd(a.dbg + 2, dbg_r1 - dbg_r0);
+    atomicAdd(a.dbg + 3, dbg_r2 - dbg_r1);
+    atomicAdd(a.dbg + 5, 1ull);
   }
+#define HCF_DBG_EPI() { if (dbg_on) atomicAdd(a.dbg + 4, __builtin_amdgcn_s_memrealtime() - dbg_r2); }
 
   // ---- epilogue (same algebra as the fp32 kernel) ---------------------------------------------
   const int cout = a.out.n;
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     // layer 1 epilogue -> split f16 A operand in LDS: record (px, kc) = [16 hi | 16 lo] halves of channels 16kc..16kc+15
     {
       const float bias1 = a.bias[oc], scale1 = a.scale[oc];
+      const float slope1 = act_slope(a.act);
       __syncthreads();                               // every wave is done with the staging buffers
       const int kc = oc >> 4, kpos = oc & 15;
 #pragma unroll
@@ -456,8 +465,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
         for (int r = 0; r < 16; ++r) {
           const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = (acc[m][r] * UNSPLIT + bias1) * scale1;
-          if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          v = apply_act(v, slope1);
           const _Float16 h = (_Float16)v;
           char* rec = lds + (px * 4 + kc) * 64 + kpos * 2;
           *reinterpret_cast<_Float16*>(rec) = h;
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   }
 
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
-  const int act = FUSE2 ? a.act2 : a.act;
+  const float slope = act_slope(FUSE2 ? a.act2 : a.act);
   if constexpr (TH == 8) {
     if (a.vec_epi) {
       // The tile goes through LDS (pixel-major fp32) so that every lane loads its residuals and stores its outputs as
@@ -539,8 +547,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
         for (int r = 0; r < 16; ++r) {
           const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
           float v = (acc[m][r] * UNSPLIT + bias) * scale;
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          v = apply_act(v, slope);
           ldsT[px * NPAD + oc] = v;
         }
       __syncthreads();
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
           *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
         }
       }
+      HCF_DBG_EPI()
       return;
     }
   }
@@ -594,8 +602,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
         if (ocok && y < H && x < W) {
           const size_t pix = (size_t)((size_t)b * H + y) * W + x;
           float v = (acc[m][r] * UNSPLIT + bias) * scale;
-          if (act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (act == ACT_LRELU) v = (v >= 0.f) ? v : v * 0.2f;
+          v = apply_act(v, slope);
           if (has1) v = v * a.rs1 + r1[q];
           if (has2) v = v * a.rs2 + r2[q];
           a.out.p[pix * a.out.cs + a.out.c0 + oc] = v;
@@ -603,6 +610,8 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       }
     }
   }
+  HCF_DBG_EPI()
+#undef HCF_DBG_EPI
 }
 
 int g_f16x3_tall = 0;   // 16-row tile variants measured no better than the 8-row tile (profiles/r01_f16x3_notes.md); bit0 NTB=1, bit1 NTB=2

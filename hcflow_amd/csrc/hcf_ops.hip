@@ -482,10 +482,10 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  a.dbg = (unsigned long long*)t.dev(4);
-  if (a.dbg) hipMemsetAsync(a.dbg, 0, 16, st);
+  a.dbg = (unsigned long long*)t.dev(16);
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 64, st);
   int rc = pack_and_launch(t, a, w.data(), cin, cout, k, srcs, n_src, st);     // pack + warm-up
-  if (a.dbg) hipMemsetAsync(a.dbg, 0, 16, st);
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 64, st);
   const bool f16 = a.ovf != nullptr;
   hipEventRecord(e0, st);
   for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
@@ -496,16 +496,19 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   if (a.dbg) {
-    unsigned long long hd[2] = {0, 0};
-    hipMemcpy(hd, a.dbg, 16, hipMemcpyDeviceToHost);
+    unsigned long long hd[6] = {0, 0, 0, 0, 0, 0};
+    hipMemcpy(hd, a.dbg, 48, hipMemcpyDeviceToHost);
     if (hd[1]) g_last_clock_mhz = 100.0 * (double)hd[0] / (double)hd[1];
+    if (hd[5])
+      fprintf(stderr, "block phases (avg of %llu blocks): prologue %.2f us, chunk loop %.2f us, epilogue %.2f us\n", hd[5],
+              hd[2] / 100.0 / hd[5], hd[3] / 100.0 / hd[5], hd[4] / 100.0 / hd[5]);
   }
   if (rc == HCF_OK && f16 && k == 3 && (g_f16x3_ablation & 32)) {
     // experiment: the same conv with split16 sources staged by LDS-DMA; a.out (regular kernel) is the reference
     ConvArgs d = a;
     for (int i = 0; i < n_src && rc == HCF_OK; ++i) {
       const size_t n = (size_t)B * H * W * a.src[i].cs;
-      d.src[i] = mkview(t.dev(n), a.src[i].cs, 0, a.src[i].n);
+      d.src[i] = as_split16(mkview(t.dev(n), a.src[i].cs, 0, a.src[i].n));
       if (!t.ok) return HCF_ERR_NOMEM;
       rc = launch_to_split16(a.src[i], d.src[i], B, H, W, st);
     }
@@ -539,9 +542,8 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
     unsigned long long hd[5] = {0, 0, 0, 0, 0};
     hipMemcpy(hd, d.dbg, 40, hipMemcpyDeviceToHost);
     if (hd[4])
-      fprintf(stderr, "dma block phases (avg of %llu blocks): prologue %.2f us, chunk loop %.2f us, epilogue %.2f us, clock %.0f MHz\n",
-              hd[4], hd[0] / 100.0 / hd[4], hd[1] / 100.0 / hd[4], hd[2] / 100.0 / hd[4],
-              100.0 * hd[3] / (double)(hd[0] + hd[1] + hd[2]));
+      fprintf(stderr, "dma tile phases (avg of %llu tiles): chunk loops %.2f us, epilogue %.2f us, clock %.0f MHz\n",
+              hd[4], hd[1] / 100.0 / hd[4], hd[2] / 100.0 / hd[4], 100.0 * hd[3] / (double)(hd[1] + hd[2]));
   }
   if (ms_per_launch) *ms_per_launch = ms / iters;
   if (flops_per_launch) *flops_per_launch = 2.0 * k * k * cin * (double)cout * B * H * W;
