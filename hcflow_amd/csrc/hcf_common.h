@@ -65,6 +65,7 @@ struct ConvArgs {
   // f16x3 kernel, set by the launcher: first-round blocks (blockIdx < stagger_blocks) sleep (workgroup slot on the CU
   // % stagger_mod) * stagger x 1024 cycles, so that the co-resident blocks run out of phase (0 = off)
   int stagger, stagger_blocks, stagger_mod;
+  int ntiles;              // f16x3 kernel, set by the launcher: output tiles (persistent variants walk them with a gridDim stride)
   int vec_epi;             // f16x3 kernel, set by the launcher: out / residual views allow 16-byte accesses -> LDS-transposed epilogue
 };
 

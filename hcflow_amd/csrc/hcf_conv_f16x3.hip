@@ -63,6 +63,9 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle 
 #ifndef HCF_SPLIT_PER_TAP
 #define HCF_SPLIT_PER_TAP 2   // staged slots split per tap in the MFMA shadow of the last taps
 #endif
+#ifndef HCF_PERSIST
+#define HCF_PERSIST 0
+#endif
 #ifndef HCF_PRESPLIT
 #define HCF_PRESPLIT 0   // 1: timing experiment only (pre-split activation format, see profiles/r01_f16x3_notes.md)
 #endif
@@ -152,26 +155,40 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int wn = (NTB == 2) ? (wave & 1) : 0;       // which 32-channel n tile
   const int H = a.H, W = a.W;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int txb = bid % tiles_x;
-  const int tyb = (bid / tiles_x) % tiles_y;
-  const int b = bid / (tiles_x * tiles_y);
-  const int x0 = txb * TW, y0 = tyb * TH;
-
+  // PERSIST (-DHCF_PERSIST=1, plain variants without upsampled sources; measured, NOT shipped): the block walks tiles
+  // blockIdx, blockIdx + gridDim, ... and loads the first chunk of its NEXT tile under the last chunk's MFMAs, so that
+  // block launch, the first-chunk HBM latency (~3 us of a 5-7 us prologue) and the store drain are paid once per block.
+  // Persistence itself is worth 5-10 % per launch, but the staged chunk has to stay in registers across the epilogue
+  // and the kernel is already at its VGPR cap: 200-250 bytes/lane of scratch appear, some of it inside the K loop,
+  // and the net result is 20-25 % slower (profiles/r01_f16x3_notes.md).
+  constexpr bool PERSIST = HCF_PERSIST && !UP && !FUSE2 && TAILC == 0 && TH == 8;
+  const int ntiles = PERSIST ? a.ntiles : (int)gridDim.x;
+  int b, x0, y0;                                     // the tile whose activations are being STAGED
   int pos[NSLOT], pix0[NSLOT];
-  unsigned okmask = 0;
-#pragma unroll
-  for (int s = 0; s < NSLOT; ++s) {
-    const int q = tid + NTHR * s;
-    const int hp = min(q >> 2, HP - 1);
-    const int hy = hp / HW, hx = hp - hy * HW;
-    const int y = y0 + hy - PAD, x = x0 + hx - PAD;
-    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-    okmask |= ok ? (1u << s) : 0u;
-    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-    pos[s] = (yc << 16) | xc;
-    pix0[s] = (b * H + yc) * W + xc;               // pixel index for sources read at full resolution
+  unsigned okmask;
+#define HCF_SET_TILE(T)                                                                           \
+  {                                                                                               \
+    const int bid_ = xcd_remap((T), ntiles);                                                      \
+    const int txb_ = bid_ % tiles_x;                                                              \
+    const int tyb_ = (bid_ / tiles_x) % tiles_y;                                                  \
+    b = bid_ / (tiles_x * tiles_y);                                                               \
+    x0 = txb_ * TW;                                                                               \
+    y0 = tyb_ * TH;                                                                               \
+    okmask = 0;                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
+      const int q = tid + NTHR * s;                                                               \
+      const int hp = min(q >> 2, HP - 1);                                                         \
+      const int hy = hp / HW, hx = hp - hy * HW;                                                  \
+      const int y = y0 + hy - PAD, x = x0 + hx - PAD;                                             \
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;                                         \
+      okmask |= ok ? (1u << s) : 0u;                                                              \
+      const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);                           \
+      pos[s] = (yc << 16) | xc;                                                                   \
+      pix0[s] = (b * H + yc) * W + xc;               /* pixel index for sources read at full resolution */ \
+    }                                                                                             \
   }
+  int tile = blockIdx.x;
+  HCF_SET_TILE(tile)
   const int uq = tid & 3;
   const int u0 = (a.src[0].n + 3) >> 2;
   const int u1 = u0 + ((a.nsrc > 1) ? ((a.src[1].n + 3) >> 2) : 0);
@@ -290,27 +307,43 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     }                                                                                             \
   }
 
+  // fragment bases (bytes): A for tile row MT*wm + m, B for this wave's n tile
+  const int abase = ((MT * wm) * HW + li) * REC + half * 16;
+  const int bbase = half * BHALF + (wn * 32 + li) * 16;
+
+  const bool dbg_on = a.dbg && (blockIdx.x & 1023) == 512 && tid == 0;     // a few mid-grid blocks
+  const unsigned long long dbg_ra = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  HCF_STAGE_LOAD(0);
+  const unsigned long long dbg_rb = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  HCF_STAGE_SPLIT();
+  const unsigned long long dbg_rc = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  HCF_STAGE_WRITE();
+  __syncthreads();
+  const unsigned long long dbg_r1 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  if (dbg_on) {
+    atomicAdd(a.dbg + 6, dbg_ra - dbg_r0);
+    atomicAdd(a.dbg + 7, dbg_rb - dbg_ra);
+    atomicAdd(a.dbg + 8, dbg_rc - dbg_rb);
+    atomicAdd(a.dbg + 9, dbg_r1 - dbg_rc);
+  }
+
+  const int nchunk = a.nchunk;
+  for (;;) {   // tiles of this block (one iteration unless PERSIST)
   f32x16 acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-  // fragment bases (bytes): A for tile row MT*wm + m, B for this wave's n tile
-  const int abase = ((MT * wm) * HW + li) * REC + half * 16;
-  const int bbase = half * BHALF + (wn * 32 + li) * 16;
-
-  HCF_STAGE_LOAD(0);
-  HCF_STAGE_SPLIT();
-  HCF_STAGE_WRITE();
-  __syncthreads();
-  const bool dbg_on = a.dbg && (blockIdx.x & 1023) == 512 && tid == 0;     // a few mid-grid blocks
-  const unsigned long long dbg_r1 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
-
-  const int nchunk = a.nchunk;
+  const int tn = PERSIST ? tile + (int)gridDim.x : ntiles;      // this block's next tile
+  const int eb = b, ex0 = x0, ey0 = y0;                          // the tile being ACCUMULATED (b, x0, y0 move on to tile tn)
+  const unsigned long long dbg_t0 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
   for (int c = 0; c < nchunk; ++c) {
-    const bool more = (c + 1 < nchunk);
-    if (more && !(HCF_ABL & 2)) HCF_STAGE_LOAD(c + 1);   // global loads fly under this chunk's MFMAs
+    const bool last = (c + 1 == nchunk);
+    const bool more = !last || tn < ntiles;           // something to stage: the next chunk, or the next tile's first chunk
+    if (more && !(HCF_ABL & 2)) {                     // global loads fly under this chunk's MFMAs
+      if (PERSIST && last) HCF_SET_TILE(tn)
+      HCF_STAGE_LOAD(last ? 0 : c + 1);
+    }
     __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
 #if HCF_SETPRIO
     __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD
@@ -417,25 +450,25 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #if HCF_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
-    if (!more) break;
+    if (last) break;                               // (a staged next-tile chunk stays in registers through the epilogue)
     if (!INTERLEAVE) HCF_STAGE_SPLIT();            // (otherwise the split already ran inside the last taps)
     if (!(HCF_ABL & 4)) __syncthreads();           // every wave has finished reading this chunk
     if (!(HCF_ABL & 2)) HCF_STAGE_WRITE();
     if (!(HCF_ABL & 4)) __syncthreads();
   }
-#undef HCF_STAGE_LOAD
-#undef HCF_STAGE_SPLIT
-#undef HCF_STAGE_WRITE
 
   unsigned long long dbg_r2 = 0ull;
-  if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], samples at [5]
+  if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], tiles at [5]
     dbg_r2 = __builtin_amdgcn_s_memrealtime();
-    atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
-    atomicAdd(a.dbg + 1, dbg_r2 - dbg_r0);
-    atomicAdd(a.dbg + 2, dbg_r1 - dbg_r0);
-    atomicAdd(a.dbg + 3, dbg_r2 - dbg_r1);
+    if (tile == (int)blockIdx.x) {
+      atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
+      atomicAdd(a.dbg + 1, dbg_r2 - dbg_r0);
+      atomicAdd(a.dbg + 2, dbg_r1 - dbg_r0);
+    }
+    atomicAdd(a.dbg + 3, dbg_r2 - dbg_t0);
     atomicAdd(a.dbg + 5, 1ull);
   }
+#undef HCF_DBG_EPI
 #define HCF_DBG_EPI() { if (dbg_on) atomicAdd(a.dbg + 4, __builtin_amdgcn_s_memrealtime() - dbg_r2); }
 
   // ---- epilogue (same algebra as the fp32 kernel) ---------------------------------------------
@@ -521,9 +554,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
-    const int y = y0 + ty, x = x0 + tx;
+    const int y = ey0 + ty, x = ex0 + tx;
     if (y < H && x < W) {
-      const size_t pix = (size_t)((size_t)b * H + y) * W + x;
+      const size_t pix = (size_t)((size_t)eb * H + y) * W + x;
       float z[TAILC], yv[TAILC];
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
       step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
@@ -534,6 +567,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
   const float slope = act_slope(FUSE2 ? a.act2 : a.act);
+  bool done_vec = false;
   if constexpr (TH == 8) {
     if (a.vec_epi) {
       // The tile goes through LDS (pixel-major fp32) so that every lane loads its residuals and stores its outputs as
@@ -554,23 +588,23 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       constexpr int C4 = NPAD / 4;
       const int n4 = a.out.n >> 2;
       const bool h1 = a.res1.p != nullptr, h2 = a.res2.p != nullptr;
-#pragma unroll
+#pragma unroll 2
       for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
         const int idx = tid + NTHR * k;
         const int px = idx / C4, c4 = idx - px * C4;
-        const int y = y0 + (px >> 5), x = x0 + (px & 31);
+        const int y = ey0 + (px >> 5), x = ex0 + (px & 31);
         f32x4 v = *reinterpret_cast<const f32x4*>(ldsT + px * NPAD + 4 * c4);
         if (y < H && x < W && c4 < n4) {
-          const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
+          const size_t pixo = (size_t)((size_t)eb * H + y) * W + x;
           if (h1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
           if (h2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
           *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
         }
       }
-      HCF_DBG_EPI()
-      return;
+      done_vec = true;
     }
   }
+  if (!done_vec) {
   // Residual reads are issued RB at a time (per lane and residual) before the first one is used: inside the
   // bounds-checked store loop each load sat behind its own s_waitcnt, i.e. 64 serialised L2/HBM latencies per
   // residual (RDB conv5: +8 % with one residual, +40 % with the RRDB skip as well). Out-of-tile lanes read a
@@ -580,7 +614,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int occ = ocok ? oc : 0;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int y = y0 + MT * wm + m;
+    const int y = ey0 + MT * wm + m;
     const int yc = y < H ? y : H - 1;
 #pragma unroll
     for (int rb = 0; rb < 16; rb += RB) {
@@ -589,8 +623,8 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           const int r = rb + q;
-          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const size_t pixc = (size_t)((size_t)b * H + yc) * W + (x < W ? x : W - 1);
+          const int x = ex0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const size_t pixc = (size_t)((size_t)eb * H + yc) * W + (x < W ? x : W - 1);
           r1[q] = has1 ? a.res1.p[pixc * a.res1.cs + a.res1.c0 + occ] : 0.f;
           r2[q] = has2 ? a.res2.p[pixc * a.res2.cs + a.res2.c0 + occ] : 0.f;
         }
@@ -598,9 +632,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int r = rb + q;
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int x = ex0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (ocok && y < H && x < W) {
-          const size_t pix = (size_t)((size_t)b * H + y) * W + x;
+          const size_t pix = (size_t)((size_t)eb * H + y) * W + x;
           float v = (acc[m][r] * UNSPLIT + bias) * scale;
           v = apply_act(v, slope);
           if (has1) v = v * a.rs1 + r1[q];
@@ -610,8 +644,20 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       }
     }
   }
+  }
   HCF_DBG_EPI()
+  if (!PERSIST || tn >= ntiles) break;
+  tile = tn;
+  if (!INTERLEAVE) HCF_STAGE_SPLIT();
+  __syncthreads();                                   // every wave is done with the transposed tile / the last chunk's fragments
+  HCF_STAGE_WRITE();
+  __syncthreads();
+  }   // tiles
 #undef HCF_DBG_EPI
+#undef HCF_SET_TILE
+#undef HCF_STAGE_LOAD
+#undef HCF_STAGE_SPLIT
+#undef HCF_STAGE_WRITE
 }
 
 int g_f16x3_tall = 0;   // 16-row tile variants measured no better than the 8-row tile (profiles/r01_f16x3_notes.md); bit0 NTB=1, bit1 NTB=2
@@ -627,12 +673,23 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
+  b.ntiles = (int)nblk;
   {
     const int per_cu = tall ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2);     // resident blocks per CU (__launch_bounds__)
     b.stagger = (g_f16x3_ablation >> 8) & 0xff;                               // tools/conv_bench.py --ablate (n << 8)
     b.stagger_mod = per_cu;
     b.stagger_blocks = 256 * per_cu;
   }
+  // persistent variants (plain, no upsampled source): one wave of resident blocks walks all tiles
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      return HCF_ERR_HIP;
+    ncu = n;
+  }
+  const long long resident = (long long)ncu * ((NTB == 1) ? 3 : 2);           // __launch_bounds__ of the 8-row variants
+  const unsigned pgrid = (unsigned)((!HCF_PERSIST || (g_f16x3_ablation & 128) || nblk < resident) ? nblk : resident);   // --ablate 128: one tile per block
   {
     auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
     b.vec_epi = !tall && !(a.tC > 0) && a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2) &&
@@ -672,11 +729,11 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   else if (tall)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
   else if (a.in_max && vec && !b.any_up)
-    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3(pgrid), dim3(256), 0, st, b);
   else if (a.in_max)
     return HCF_ERR_UNSUPPORTED;
   else if (vec && !b.any_up)
-    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3(pgrid), dim3(256), 0, st, b);
   else if (vec)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else

@@ -482,10 +482,10 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  a.dbg = (unsigned long long*)t.dev(16);
-  if (a.dbg) hipMemsetAsync(a.dbg, 0, 64, st);
+  a.dbg = (unsigned long long*)t.dev(32);
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 128, st);
   int rc = pack_and_launch(t, a, w.data(), cin, cout, k, srcs, n_src, st);     // pack + warm-up
-  if (a.dbg) hipMemsetAsync(a.dbg, 0, 64, st);
+  if (a.dbg) hipMemsetAsync(a.dbg, 0, 128, st);
   const bool f16 = a.ovf != nullptr;
   hipEventRecord(e0, st);
   for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
@@ -496,8 +496,11 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   if (a.dbg) {
-    unsigned long long hd[6] = {0, 0, 0, 0, 0, 0};
-    hipMemcpy(hd, a.dbg, 48, hipMemcpyDeviceToHost);
+    unsigned long long hd[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpy(hd, a.dbg, 80, hipMemcpyDeviceToHost);
+    if (hd[5] && hd[6])
+      fprintf(stderr, "prologue parts: setup %.2f us, load issue %.2f us, wait + split %.2f us, LDS write + barrier %.2f us\n",
+              hd[6] / 100.0 / hd[5], hd[7] / 100.0 / hd[5], hd[8] / 100.0 / hd[5], hd[9] / 100.0 / hd[5]);
     if (hd[1]) g_last_clock_mhz = 100.0 * (double)hd[0] / (double)hd[1];
     if (hd[5])
       fprintf(stderr, "block phases (avg of %llu blocks): prologue %.2f us, chunk loop %.2f us, epilogue %.2f us\n", hd[5],
