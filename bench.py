@@ -194,7 +194,7 @@ def main():
             kname, peak = "hcf::conv_mfma_kernel<9, 2, true> (3x3, 33..64 out-ch, fp32 MFMA 32x32x2)", PEAK_F32_MFMA_TFLOPS
             pnote = "fp32 matrix peak (MI355X_MICROARCH.md)"
         else:
-            kname, peak = ("hcf::f16x3::conv_f16x3_kernel<2, true, false, false, 0, 8> (3x3, 33..64 out-ch, 3x f16 MFMA "
+            kname, peak = ("hcf::f16x3::conv_f16x3_kernel<2, true, false, false, 0, 8, false> (3x3, 33..64 out-ch, 3x f16 MFMA "
                            "32x32x16 per fp32 product block)"), PEAK_F16_MFMA_TFLOPS / 3
             pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts "
                      "ALGORITHMIC flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that")

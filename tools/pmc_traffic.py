@@ -20,7 +20,7 @@ FETCH_FIX = 2.0        # gfx950: 128-B read requests are tallied as 64 B
 
 
 def short_name(k):
-    m = re.search(r"conv_f16x3_kernel<(\d), (true|false), (true|false), (true|false), (\d+), (\d+)>", k)
+    m = re.search(r"conv_f16x3_kernel<(\d), (true|false), (true|false), (true|false), (\d+), (\d+)(?:, (?:true|false))?>", k)
     if m:
         ntb, vec, up, fuse2, tailc, th = m.groups()
         tag = "f16x3<%s>" % ntb
