@@ -140,14 +140,6 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   char* const ldsB = lds + A_BYTES;
 
   const int tid = threadIdx.x;
-  if (a.stagger > 0 && (int)blockIdx.x < a.stagger_blocks) {
-    // HW_REG_HW_ID (id 4) bits 19:16 = TG_ID, the workgroup's slot on its CU: the first round of blocks starts in
-    // lock-step, and since every block takes the same time they would stay in phase (all in their prologue /
-    // epilogue together, the MFMA pipe idle) for the whole launch
-    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
-    const int n = (int)(tg % (unsigned)a.stagger_mod) * a.stagger;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
   const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -674,12 +666,6 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   b.any_up = 0;
   b.ntiles = (int)nblk;
-  {
-    const int per_cu = tall ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2);     // resident blocks per CU (__launch_bounds__)
-    b.stagger = (g_f16x3_ablation >> 8) & 0xff;                               // tools/conv_bench.py --ablate (n << 8)
-    b.stagger_mod = per_cu;
-    b.stagger_blocks = 256 * per_cu;
-  }
   // persistent variants (plain, no upsampled source): one wave of resident blocks walks all tiles
   static int ncu = 0;
   if (!ncu) {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NTHR, 1) void conv_f16x3_dma_kernel(const ConvArgs 
   const gcptr wq = uniform_ptr(a.wpack);
   const gcptr zpage = uniform_ptr(a.zeros);
   const int nchunk = a.nchunk;
-  const int dbgbits = __builtin_amdgcn_readfirstlane(a.stagger);   // timing ablations: 1 no DMA in the loop, 2 fragments read at tap 0 only, 4 no global stores, 8 no LDS transposition writes
+  const int dbgbits = __builtin_amdgcn_readfirstlane(a.dbg_bits);   // timing ablations: 1 no DMA in the loop, 2 fragments read at tap 0 only, 4 no global stores, 8 no LDS transposition writes
 
   // tile id -> (image, tile row, tile col); XCD-aware: the tiles one XCD works on are neighbours in memory
 #define HCF_TILE_COORDS(T, TB, TY0, TX0)                                                          \

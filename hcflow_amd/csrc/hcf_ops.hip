@@ -522,7 +522,7 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
     if (!t.ok) return HCF_ERR_NOMEM;
     d.dbg = (unsigned long long*)t.dev(16);
     if (!t.ok) return HCF_ERR_NOMEM;
-    d.stagger = (g_f16x3_ablation >> 8) & 0xff;
+    d.dbg_bits = (g_f16x3_ablation >> 8) & 0xff;
     hipMemsetAsync(diff, 0, 4, st);
     hipMemsetAsync(d.out.p, 0, nout * 4, st);
     hipMemsetAsync(a.out.p, 0, nout * 4, st);
