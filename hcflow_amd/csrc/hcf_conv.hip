@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NSLOT = (NLOAD + 255) / 256;
   constexpr int NPAD = NT * 32;
   constexpr int KSTEPS = TAPS * 2;                 // (tap, 8-channel group) steps per chunk
-  __shared__ __attribute__((aligned(16))) float lds[2][HP * KC];
+  // the epilogue re-uses the staging LDS for the transposed output tile (16-byte stores, float4 residual reads) where
+  // that costs no occupancy: 32-channel tiles fit as is, the 3x3 64-channel tile grows 43.5 -> 64 KB (2 blocks/CU either way)
+  constexpr bool VEC_EPI = (NT == 1) || (NT == 2 && TAPS == 9);
+  constexpr int E_FLOATS = VEC_EPI ? TH * TW * NPAD : 0;
+  constexpr int LDS_FLOATS = (2 * HP * KC > E_FLOATS) ? 2 * HP * KC : E_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds_raw[LDS_FLOATS];
+  float (*const lds)[HP * KC] = reinterpret_cast<float (*)[HP * KC]>(lds_raw);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
@@ -213,6 +219,40 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const bool has1 = a.res1.p != nullptr, has2 = a.res2.p != nullptr;
   constexpr int RB = 8;
   const float slope = act_slope(a.act);
+  if constexpr (VEC_EPI) {
+    if (a.vec_epi) {
+      __syncthreads();                               // (the K loop ends on a barrier; kept explicit for the LDS re-use)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int oc = n * 32 + li;
+        const float bias = a.bias[oc], scale = a.scale[oc];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = (2 * wave + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
+            lds_raw[px * NPAD + oc] = apply_act((acc[m][n][r] + bias) * scale, slope);
+          }
+      }
+      __syncthreads();
+      constexpr int C4 = NPAD / 4;
+      const int n4 = cout >> 2;
+#pragma unroll 2
+      for (int k = 0; k < (TH * TW * C4) / 256; ++k) {
+        const int idx = tid + 256 * k;
+        const int px = idx / C4, c4 = idx - px * C4;
+        const int y = y0 + (px >> 5), x = x0 + (px & 31);
+        f32x4 v = *reinterpret_cast<const f32x4*>(lds_raw + px * NPAD + 4 * c4);
+        if (y < H && x < W && c4 < n4) {
+          const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
+          if (has1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
+          if (has2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
+          *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     const int oc = n * 32 + li;
@@ -260,12 +300,17 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   const long long nblk = (long long)a.B * tiles_x * tiles_y;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;
   bool vec = true;
-  for (int i = 0; i < a.nsrc; ++i)
+  for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
+    if (a.src[i].fmt != 0) return HCF_ERR_ARG;      // split16 tensors belong to the f16x3 LDS-DMA kernel
+  }
+  ConvArgs b = a;
+  auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
+  b.vec_epi = a.out.p && (a.out.n & 3) == 0 && a.out.fmt == 0 && v4(a.out) && v4(a.res1) && v4(a.res2);
   if (vec)
-    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NT, true>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NT, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NT, false>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NT, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
