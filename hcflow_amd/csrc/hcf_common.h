@@ -116,6 +116,13 @@ struct RepackArgs {
   _Float16* pk16;          // f16x3 pack or nullptr
 };
 int launch_repack_conv(const RepackArgs& a, hipStream_t st);
+// batched forms for the per-step refresh of a training run (thousands of tiny repacks -> three launches): job tables live
+// in device memory; prefix[j] = first block of job j, prefix[njobs] = total blocks
+struct RepackEpiJob { int kind, cout; const float* b; const float* l; float* bias; float* scale; };
+struct CopyJob { const float* src; float* dst; int n; };
+int launch_repack_conv_batch(const RepackArgs* jobs, const long long* prefix, int njobs, long long nblocks, hipStream_t st);
+int launch_repack_epilogue_batch(const RepackEpiJob* jobs, int njobs, hipStream_t st);
+int launch_copy_jobs(const CopyJob* jobs, int njobs, hipStream_t st);      // dst[0..n) = src[0..n) per job (gather / scatter of small tables)
 int launch_repack_epilogue(int kind, const float* b, const float* l, int cout, float* bias, float* scale, hipStream_t st);
 
 // ---- flow-step glue --------------------------------------------------------------------------

@@ -528,6 +528,7 @@ struct hcf_engine {
   void free_weights() {
     for (float* p : dev_allocs) hipFree(p);
     dev_allocs.clear();
+    ++refresh_gen;                           // the cached refresh job tables point into these allocations
     unit_dev = nullptr;
     weight_bytes = 0;
   }
@@ -1135,6 +1136,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->garena.base) hipFree(e->garena.base);
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
+  if (e->rt.blob) hipFree(e->rt.blob);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }
@@ -1290,6 +1292,7 @@ int hcf_train_backward_inverse(hcf_engine* e, const float* grad_out, float* dpar
 int hcf_bind_param_device(hcf_engine* e, const char* key, const float* dev_ptr) {
   if (!e || !key) return HCF_ERR_ARG;
   if (!e->params.count(key)) return e->fail(HCF_ERR_KEY, std::string("unknown parameter: ") + key);
+  if (e->dev_src[key] != dev_ptr) ++e->refresh_gen;      // the cached refresh job tables hold this pointer
   e->dev_src[key] = dev_ptr;
   return HCF_OK;
 }

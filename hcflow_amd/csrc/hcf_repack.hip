@@ -13,10 +13,9 @@ __device__ __forceinline__ float logical_weight(const RepackArgs& a, int n, int 
   return a.w[((size_t)ci * a.cin_w + a.off + n) * a.taps + (a.taps - 1 - t)];
 }
 
-__global__ __launch_bounds__(256) void repack_conv_kernel(const RepackArgs a) {
-  // one thread per (chunk, tap, n, e in 0..15)
+// one thread per (chunk, tap, n, e in 0..15) of one pack
+__device__ __forceinline__ void repack_one(const RepackArgs& a, long long i) {
   const long long total = (long long)a.nchunk * a.taps * a.cout * 16;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int e = (int)(i & 15);
   const int n = (int)((i >> 4) % a.cout);
@@ -42,6 +41,22 @@ __global__ __launch_bounds__(256) void repack_conv_kernel(const RepackArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void repack_conv_kernel(const RepackArgs a) {
+  repack_one(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// every pack of the net in one launch: the block looks its job up in the block-prefix table (binary search, <= 12 steps)
+__global__ __launch_bounds__(256) void repack_conv_batch_kernel(const RepackArgs* jobs, const long long* prefix, int njobs) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = njobs;                       // invariant: prefix[lo] <= blk < prefix[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const RepackArgs a = jobs[lo];
+  repack_one(a, (blk - prefix[lo]) * 256 + threadIdx.x);
+}
+
 int launch_repack_conv(const RepackArgs& a, hipStream_t st) {
   if (!a.w || a.cout < 1 || a.nchunk < 1) return HCF_ERR_ARG;
   const long long total = (long long)a.nchunk * a.taps * a.cout * 16;
@@ -60,6 +75,37 @@ __global__ void repack_epilogue_kernel(int kind, const float* b, const float* l,
 int launch_repack_epilogue(int kind, const float* b, const float* l, int cout, float* bias, float* scale, hipStream_t st) {
   if (kind != 0 && !l) return HCF_ERR_ARG;
   hipLaunchKernelGGL(repack_epilogue_kernel, dim3((unsigned)((cout + 63) / 64)), dim3(64), 0, st, kind, b, l, cout, bias, scale);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+int launch_repack_conv_batch(const RepackArgs* jobs, const long long* prefix, int njobs, long long nblocks, hipStream_t st) {
+  if (!jobs || !prefix || njobs < 1 || nblocks < 1 || nblocks > 0x7fffffffLL) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(repack_conv_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs, prefix, njobs);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+__global__ void repack_epilogue_batch_kernel(const RepackEpiJob* jobs) {
+  const RepackEpiJob j = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < j.cout; c += blockDim.x) {
+    j.bias[c] = j.b ? j.b[c] : 0.f;
+    j.scale[c] = (j.kind == 1) ? expf(j.l[c]) : (j.kind == 2) ? expf(3.f * j.l[c]) : 1.f;
+  }
+}
+
+int launch_repack_epilogue_batch(const RepackEpiJob* jobs, int njobs, hipStream_t st) {
+  if (!jobs || njobs < 1) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(repack_epilogue_batch_kernel, dim3((unsigned)njobs), dim3(64), 0, st, jobs);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+__global__ void copy_jobs_kernel(const CopyJob* jobs) {
+  const CopyJob j = jobs[blockIdx.x];
+  for (int i = threadIdx.x; i < j.n; i += blockDim.x) j.dst[i] = j.src[i];
+}
+
+int launch_copy_jobs(const CopyJob* jobs, int njobs, hipStream_t st) {
+  if (!jobs || njobs < 1) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(copy_jobs_kernel, dim3((unsigned)njobs), dim3(128), 0, st, jobs);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
