@@ -63,7 +63,6 @@ struct ConvArgs {
   const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
   unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
   int dbg_bits;            // hcf_conv_f16x3_dma.hip timing ablations (tools/conv_bench.py --ablate (bits << 8) | 32), 0 = off
-  int ntiles;              // f16x3 kernel, set by the launcher: output tiles (persistent variants walk them with a gridDim stride)
   int vec_epi;             // f16x3 kernel, set by the launcher: out / residual views allow 16-byte accesses -> LDS-transposed epilogue
 };
 

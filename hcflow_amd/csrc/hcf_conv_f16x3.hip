@@ -31,6 +31,9 @@
 //     a_lo b_hi); the 2^-11 is applied in the epilogue.
 //   * Waves: NTB = 2 (33..64 out channels): wave = (row half, n tile), 4 row tiles each;
 //     NTB = 1: 4 waves x 2 row tiles.
+//   * Epilogue: the fp32 tile is transposed through LDS (free after the K loop) so that every lane reads its
+//     residuals and stores its outputs as 16 contiguous bytes, with a branch-free activation; views that are not
+//     16-byte addressable (odd channel counts) keep a scalar epilogue whose residual reads go out 8 at a time.
 //   * |a| >= 65504 cannot be represented by the hi part and turns the accumulators it touches into
 //     inf / NaN; the epilogue tests the raw accumulators and raises a device flag, upon which the engine
 //     re-runs the pass on the exact fp32 kernel (hcf_conv.hip).
@@ -51,27 +54,9 @@ typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;
 
 int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle the tall-tile variants, see launch_t)
 
-#ifndef HCF_SETPRIO
-#define HCF_SETPRIO 1
-#endif
-#ifndef HCF_DXMAJOR
-#define HCF_DXMAJOR 0   // 1: dx-major sliding-window tap loop (fewer LDS reads, same speed: profiles/r01_f16x3_notes.md v9)
-#endif
-#ifndef HCF_DX_PIN
-#define HCF_DX_PIN 2
-#endif
-#ifndef HCF_SPLIT_PER_TAP
-#define HCF_SPLIT_PER_TAP 2   // staged slots split per tap in the MFMA shadow of the last taps
-#endif
-#ifndef HCF_PERSIST
-#define HCF_PERSIST 0
-#endif
-#ifndef HCF_PRESPLIT
-#define HCF_PRESPLIT 0   // 1: timing experiment only (pre-split activation format, see profiles/r01_f16x3_notes.md)
-#endif
-#ifndef HCF_ABL
-#define HCF_ABL 0     // timing ablations, build with -DHCF_ABL=bits: 1 no weight staging, 2 no activation staging, 4 no barriers
-#endif
+// Variants measured and NOT kept (profiles/r01_f16x3_notes.md has the numbers; the code is in the history):
+// a dx-major sliding-window tap loop (fewer LDS reads, same time), a pre-split activation format with register staging,
+// persistent blocks with the next tile's first chunk prefetched (VGPR cap: spills), a first-round block stagger.
 
 namespace f16x3 {
 
@@ -147,40 +132,26 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int wn = (NTB == 2) ? (wave & 1) : 0;       // which 32-channel n tile
   const int H = a.H, W = a.W;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  // PERSIST (-DHCF_PERSIST=1, plain variants without upsampled sources; measured, NOT shipped): the block walks tiles
-  // blockIdx, blockIdx + gridDim, ... and loads the first chunk of its NEXT tile under the last chunk's MFMAs, so that
-  // block launch, the first-chunk HBM latency (~3 us of a 5-7 us prologue) and the store drain are paid once per block.
-  // Persistence itself is worth 5-10 % per launch, but the staged chunk has to stay in registers across the epilogue
-  // and the kernel is already at its VGPR cap: 200-250 bytes/lane of scratch appear, some of it inside the K loop,
-  // and the net result is 20-25 % slower (profiles/r01_f16x3_notes.md).
-  constexpr bool PERSIST = HCF_PERSIST && !UP && !FUSE2 && TAILC == 0 && TH == 8;
-  const int ntiles = PERSIST ? a.ntiles : (int)gridDim.x;
-  int b, x0, y0;                                     // the tile whose activations are being STAGED
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int txb = bid % tiles_x;
+  const int tyb = (bid / tiles_x) % tiles_y;
+  const int b = bid / (tiles_x * tiles_y);
+  const int x0 = txb * TW, y0 = tyb * TH;
+
   int pos[NSLOT], pix0[NSLOT];
-  unsigned okmask;
-#define HCF_SET_TILE(T)                                                                           \
-  {                                                                                               \
-    const int bid_ = xcd_remap((T), ntiles);                                                      \
-    const int txb_ = bid_ % tiles_x;                                                              \
-    const int tyb_ = (bid_ / tiles_x) % tiles_y;                                                  \
-    b = bid_ / (tiles_x * tiles_y);                                                               \
-    x0 = txb_ * TW;                                                                               \
-    y0 = tyb_ * TH;                                                                               \
-    okmask = 0;                                                                                   \
-    _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
-      const int q = tid + NTHR * s;                                                               \
-      const int hp = min(q >> 2, HP - 1);                                                         \
-      const int hy = hp / HW, hx = hp - hy * HW;                                                  \
-      const int y = y0 + hy - PAD, x = x0 + hx - PAD;                                             \
-      const bool ok = y >= 0 && y < H && x >= 0 && x < W;                                         \
-      okmask |= ok ? (1u << s) : 0u;                                                              \
-      const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);                           \
-      pos[s] = (yc << 16) | xc;                                                                   \
-      pix0[s] = (b * H + yc) * W + xc;               /* pixel index for sources read at full resolution */ \
-    }                                                                                             \
+  unsigned okmask = 0;
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int q = tid + NTHR * s;
+    const int hp = min(q >> 2, HP - 1);
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int y = y0 + hy - PAD, x = x0 + hx - PAD;
+    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+    okmask |= ok ? (1u << s) : 0u;
+    const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+    pos[s] = (yc << 16) | xc;
+    pix0[s] = (b * H + yc) * W + xc;               // pixel index for sources read at full resolution
   }
-  int tile = blockIdx.x;
-  HCF_SET_TILE(tile)
   const int uq = tid & 3;
   const int u0 = (a.src[0].n + 3) >> 2;
   const int u1 = u0 + ((a.nsrc > 1) ? ((a.src[1].n + 3) >> 2) : 0);
@@ -239,11 +210,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       stg[s] = v; /* RAW load result: nothing here may consume it, or the wave waits for HBM now */ \
     }                                                                                             \
     stg_valid = valid;                                                                            \
-    if (!(HCF_ABL & 1)) {                                                                         \
-      _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                         \
-        const int q = tid + NTHR * s;                                                             \
-        stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? NTHR * s : 0)];                            \
-      }                                                                                           \
+    _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
+      const int q = tid + NTHR * s;                                                               \
+      stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? NTHR * s : 0)];                              \
     }                                                                                             \
   }
   // split one staged slot in registers (VALU only): stg[s] <- {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves.
@@ -259,18 +228,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       v.w = 0.f;                                                                                  \
     }                                                                                             \
     union { f16x4 h[2]; f32x4 f; } u_;                                                            \
-    if (HCF_PRESPLIT) { /* timing experiment: the tensor already holds [16 hi | 16 lo] f16 per 16-channel chunk */ \
-      u_.f = v;                                                                                   \
-    } else if (HCF_ABL & 8) { /* timing only: pretend the tensor is stored pre-split (bit mask instead of the split) */ \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                               \
-        v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[e]) & 0x33ff33ffu);        \
-      u_.f = v;                                                                                   \
-    } else {                                                                                      \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
-        const _Float16 h = (_Float16)v[e];                                                        \
-        u_.h[0][e] = h;                                                                           \
-        u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                 \
-      }                                                                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
+      const _Float16 h = (_Float16)v[e];                                                          \
+      u_.h[0][e] = h;                                                                             \
+      u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                   \
     }                                                                                             \
     stg[S] = u_.f;                                                                                \
   }
@@ -282,15 +243,11 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                           \
       const int q = tid + NTHR * s;                                                               \
       if (q < NLOAD) {                                                                            \
-        if (HCF_PRESPLIT) { /* one 16-byte piece straight into the record */                      \
-          *reinterpret_cast<f32x4*>(lds + (q >> 2) * REC + (q & 3) * 16) = stg[s];                 \
-        } else {                                                                                  \
         char* rec = lds + (q >> 2) * REC + (q & 3) * 8;                                           \
         union { f16x4 h[2]; f32x4 f; } u_;                                                        \
         u_.f = stg[s];                                                                            \
         *reinterpret_cast<f16x4*>(rec) = u_.h[0];                                                 \
         *reinterpret_cast<f16x4*>(rec + 32) = u_.h[1];                                            \
-        }                                                                                         \
       }                                                                                           \
     }                                                                                             \
     _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
@@ -319,91 +276,18 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     atomicAdd(a.dbg + 9, dbg_r1 - dbg_rc);
   }
 
-  const int nchunk = a.nchunk;
-  for (;;) {   // tiles of this block (one iteration unless PERSIST)
   f32x16 acc[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-  const int tn = PERSIST ? tile + (int)gridDim.x : ntiles;      // this block's next tile
-  const int eb = b, ex0 = x0, ey0 = y0;                          // the tile being ACCUMULATED (b, x0, y0 move on to tile tn)
-  const unsigned long long dbg_t0 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  const int nchunk = a.nchunk;
   for (int c = 0; c < nchunk; ++c) {
-    const bool last = (c + 1 == nchunk);
-    const bool more = !last || tn < ntiles;           // something to stage: the next chunk, or the next tile's first chunk
-    if (more && !(HCF_ABL & 2)) {                     // global loads fly under this chunk's MFMAs
-      if (PERSIST && last) HCF_SET_TILE(tn)
-      HCF_STAGE_LOAD(last ? 0 : c + 1);
-    }
+    const bool more = (c + 1 < nchunk);
+    if (more) HCF_STAGE_LOAD(c + 1);               // global loads fly under this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
-#if HCF_SETPRIO
-    __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD
-#endif
-#if HCF_DXMAJOR
-    // dx-major with a sliding row window: for one dx the three dy taps touch pixel rows dy .. dy+MT-1 of the
-    // wave's MT+2 halo rows, so each row fragment is read from LDS once per dx (3 (MT+2) A reads per chunk
-    // instead of 9 MT) and every stage prefetches what the NEXT stage needs (one new row, the next tap's
-    // weights; at dy = 2 the first MT rows of the next dx) -- LDS reads, not MFMAs, burn most of the power.
-    {
-      f16x8 rh[3][MT + 2], rl[3][MT + 2], wb1[9], wb2[9];
-#define HCF_LD_ROW(DX, R)                                                                \
-      {                                                                                  \
-        const char* rec_ = lds + abase + ((R) * HW + (DX)) * REC;                        \
-        rh[DX][R] = *reinterpret_cast<const f16x8*>(rec_);                               \
-        rl[DX][R] = *reinterpret_cast<const f16x8*>(rec_ + 32);                          \
-      }
-#define HCF_LD_B(DX, DY)                                                                 \
-      {                                                                                  \
-        const char* bt_ = ldsB + bbase + ((DY) * 3 + (DX)) * (4 * BHALF);                \
-        wb1[(DX) * 3 + (DY)] = *reinterpret_cast<const f16x8*>(bt_);                     \
-        wb2[(DX) * 3 + (DY)] = *reinterpret_cast<const f16x8*>(bt_ + 2 * BHALF);         \
-      }
-      HCF_LD_B(0, 0)
-#pragma unroll
-      for (int r = 0; r < MT; ++r) HCF_LD_ROW(0, r)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int stage = dx * 3 + dy;
-          // prefetch for the next stage
-          if (dy < 2) {
-            HCF_LD_B(dx, dy + 1)
-            HCF_LD_ROW(dx, MT + dy)
-          } else if (dx < 2) {
-            HCF_LD_B(dx + 1, 0)
-#pragma unroll
-            for (int r = 0; r < MT; ++r) HCF_LD_ROW(dx + 1, r)
-          }
-#if HCF_DX_PIN >= 2
-          __builtin_amdgcn_sched_barrier(0);      // ... and the prefetch is issued BEFORE this stage's MFMAs
-#endif
-          // the split of the NEXT chunk's staged slots rides in the MFMA shadow of the last stages
-          if (INTERLEAVE && more && !(HCF_ABL & 2) && stage >= TAPS - (NSLOT + 1) / 2) {
-            const int s0 = 2 * (stage - (TAPS - (NSLOT + 1) / 2));
-            if (s0 < NSLOT) HCF_SPLIT_SLOT(s0)
-            if (s0 + 1 < NSLOT) HCF_SPLIT_SLOT(s0 + 1)
-          }
-          const f16x8 b1 = wb1[stage], b2 = wb2[stage];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)   // a_hi * (b_hi 2^11)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[dx][m + dy], b1, acc[m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < MT; ++m)   // a_hi * (b_lo 2^11)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh[dx][m + dy], b2, acc[m], 0, 0, 0);
-#pragma unroll
-          for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl[dx][m + dy], b1, acc[m], 0, 0, 0);
-#if HCF_DX_PIN
-          __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance: nothing moves across stages
-#endif
-        }
-      }
-#undef HCF_LD_ROW
-#undef HCF_LD_B
-    }
-#else
+    __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD (+2 %)
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int dy = t / 3, dx = t % 3;
@@ -419,11 +303,12 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       }
       // the split of the NEXT chunk's staged slots rides in the MFMA shadow of the last taps (its loads were
       // issued a whole chunk of MFMAs earlier); two slots per tap
-      constexpr int SPLIT_T0 = TAPS - (NSLOT + HCF_SPLIT_PER_TAP - 1) / HCF_SPLIT_PER_TAP;
-      if (INTERLEAVE && more && !(HCF_ABL & 2) && t >= SPLIT_T0) {
+      constexpr int SPT = 2;                         // slots per tap (3 or 6, i.e. a later start, measured the same)
+      constexpr int SPLIT_T0 = TAPS - (NSLOT + SPT - 1) / SPT;
+      if (INTERLEAVE && more && t >= SPLIT_T0) {
 #pragma unroll
-        for (int q = 0; q < HCF_SPLIT_PER_TAP; ++q) {
-          const int sq = HCF_SPLIT_PER_TAP * (t - SPLIT_T0) + q;
+        for (int q = 0; q < SPT; ++q) {
+          const int sq = SPT * (t - SPLIT_T0) + q;
           if (sq < NSLOT) HCF_SPLIT_SLOT(sq)
         }
       }
@@ -438,29 +323,26 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       for (int m = 0; m < MT; ++m)   // a_lo * (b_hi 2^11)
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[m], b1, acc[m], 0, 0, 0);
     }
-#endif
-#if HCF_SETPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
-    if (last) break;                               // (a staged next-tile chunk stays in registers through the epilogue)
+    if (!more) break;
     if (!INTERLEAVE) HCF_STAGE_SPLIT();            // (otherwise the split already ran inside the last taps)
-    if (!(HCF_ABL & 4)) __syncthreads();           // every wave has finished reading this chunk
-    if (!(HCF_ABL & 2)) HCF_STAGE_WRITE();
-    if (!(HCF_ABL & 4)) __syncthreads();
+    __syncthreads();                               // every wave has finished reading this chunk
+    HCF_STAGE_WRITE();
+    __syncthreads();
   }
+#undef HCF_STAGE_LOAD
+#undef HCF_STAGE_SPLIT
+#undef HCF_STAGE_WRITE
 
   unsigned long long dbg_r2 = 0ull;
-  if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], tiles at [5]
+  if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], blocks at [5]
     dbg_r2 = __builtin_amdgcn_s_memrealtime();
-    if (tile == (int)blockIdx.x) {
-      atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
-      atomicAdd(a.dbg + 1, dbg_r2 - dbg_r0);
-      atomicAdd(a.dbg + 2, dbg_r1 - dbg_r0);
-    }
-    atomicAdd(a.dbg + 3, dbg_r2 - dbg_t0);
+    atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
+    atomicAdd(a.dbg + 1, dbg_r2 - dbg_r0);
+    atomicAdd(a.dbg + 2, dbg_r1 - dbg_r0);
+    atomicAdd(a.dbg + 3, dbg_r2 - dbg_r1);
     atomicAdd(a.dbg + 5, 1ull);
   }
-#undef HCF_DBG_EPI
 #define HCF_DBG_EPI() { if (dbg_on) atomicAdd(a.dbg + 4, __builtin_amdgcn_s_memrealtime() - dbg_r2); }
 
   // ---- epilogue (same algebra as the fp32 kernel) ---------------------------------------------
@@ -546,9 +428,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
-    const int y = ey0 + ty, x = ex0 + tx;
+    const int y = y0 + ty, x = x0 + tx;
     if (y < H && x < W) {
-      const size_t pix = (size_t)((size_t)eb * H + y) * W + x;
+      const size_t pix = (size_t)((size_t)b * H + y) * W + x;
       float z[TAILC], yv[TAILC];
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
       step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
@@ -584,10 +466,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
         const int idx = tid + NTHR * k;
         const int px = idx / C4, c4 = idx - px * C4;
-        const int y = ey0 + (px >> 5), x = ex0 + (px & 31);
+        const int y = y0 + (px >> 5), x = x0 + (px & 31);
         f32x4 v = *reinterpret_cast<const f32x4*>(ldsT + px * NPAD + 4 * c4);
         if (y < H && x < W && c4 < n4) {
-          const size_t pixo = (size_t)((size_t)eb * H + y) * W + x;
+          const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
           if (h1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
           if (h2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
           *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
@@ -606,7 +488,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int occ = ocok ? oc : 0;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int y = ey0 + MT * wm + m;
+    const int y = y0 + MT * wm + m;
     const int yc = y < H ? y : H - 1;
 #pragma unroll
     for (int rb = 0; rb < 16; rb += RB) {
@@ -615,8 +497,8 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           const int r = rb + q;
-          const int x = ex0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const size_t pixc = (size_t)((size_t)eb * H + yc) * W + (x < W ? x : W - 1);
+          const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const size_t pixc = (size_t)((size_t)b * H + yc) * W + (x < W ? x : W - 1);
           r1[q] = has1 ? a.res1.p[pixc * a.res1.cs + a.res1.c0 + occ] : 0.f;
           r2[q] = has2 ? a.res2.p[pixc * a.res2.cs + a.res2.c0 + occ] : 0.f;
         }
@@ -624,9 +506,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int r = rb + q;
-        const int x = ex0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (ocok && y < H && x < W) {
-          const size_t pix = (size_t)((size_t)eb * H + y) * W + x;
+          const size_t pix = (size_t)((size_t)b * H + y) * W + x;
           float v = (acc[m][r] * UNSPLIT + bias) * scale;
           v = apply_act(v, slope);
           if (has1) v = v * a.rs1 + r1[q];
@@ -638,18 +520,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   }
   }
   HCF_DBG_EPI()
-  if (!PERSIST || tn >= ntiles) break;
-  tile = tn;
-  if (!INTERLEAVE) HCF_STAGE_SPLIT();
-  __syncthreads();                                   // every wave is done with the transposed tile / the last chunk's fragments
-  HCF_STAGE_WRITE();
-  __syncthreads();
-  }   // tiles
 #undef HCF_DBG_EPI
-#undef HCF_SET_TILE
-#undef HCF_STAGE_LOAD
-#undef HCF_STAGE_SPLIT
-#undef HCF_STAGE_WRITE
 }
 
 int g_f16x3_tall = 0;   // 16-row tile variants measured no better than the 8-row tile (profiles/r01_f16x3_notes.md); bit0 NTB=1, bit1 NTB=2
@@ -665,17 +536,6 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
-  b.ntiles = (int)nblk;
-  // persistent variants (plain, no upsampled source): one wave of resident blocks walks all tiles
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
-      return HCF_ERR_HIP;
-    ncu = n;
-  }
-  const long long resident = (long long)ncu * ((NTB == 1) ? 3 : 2);           // __launch_bounds__ of the 8-row variants
-  const unsigned pgrid = (unsigned)((!HCF_PERSIST || (g_f16x3_ablation & 128) || nblk < resident) ? nblk : resident);   // --ablate 128: one tile per block
   {
     auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
     b.vec_epi = !tall && !(a.tC > 0) && a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2) &&
@@ -715,11 +575,11 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   else if (tall)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
   else if (a.in_max && vec && !b.any_up)
-    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3(pgrid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else if (a.in_max)
     return HCF_ERR_UNSUPPORTED;
   else if (vec && !b.any_up)
-    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3(pgrid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else if (vec)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else
