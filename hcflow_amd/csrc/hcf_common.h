@@ -68,10 +68,14 @@ struct ConvArgs {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 // Branch-free activation for unrolled epilogues: a runtime `if (act == ...)` chain per accumulator compiles to a chain of
-// scalar branches PER VALUE (~6 us of a 64-channel tile's epilogue). act(v) = max(v, 0) + slope * min(v, 0) is exact
-// for all three cases (one of the two terms is always zero).
+// scalar branches PER VALUE (~6 us of a 64-channel tile's epilogue). One select on a per-launch slope instead; NaN
+// propagates (as torch's relu / leaky_relu do), relu(-inf) = 0.
 __device__ __forceinline__ float act_slope(int act) { return act == ACT_RELU ? 0.f : act == ACT_LRELU ? 0.2f : 1.f; }
-__device__ __forceinline__ float apply_act(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float apply_act(float v, float slope) {
+  // v > 0 or NaN -> v; otherwise slope * v, with relu's -inf clamped first so that 0 * -inf cannot make a NaN
+  const float lo = (slope == 0.f) ? -3.0e38f : -INFINITY;          // loop-invariant
+  return !(v <= 0.f) ? v : slope * fmaxf(v, lo);
+}
 enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);

@@ -87,6 +87,31 @@ def test_conv2d_residual_epilogues(dev):
     assert _rel(o1, ref1) <= 1e-5 and _rel(o2, ref2) <= 1e-5
 
 
+@pytest.mark.parametrize("act", [None, "relu", "lrelu"])
+@pytest.mark.parametrize("cout", [32, 12])          # 16-byte (LDS-transposed) and scalar epilogue
+def test_conv2d_non_finite_values_propagate_like_torch(dev, act, cout):
+    """NaN / inf pre-activations must come out as torch's conv + activation produce them (the branch-free activation in
+    the epilogue may not swallow a NaN; relu(-inf) = 0)."""
+    from hcflow_amd import ops
+    g = _gen(11)
+    x = torch.randn(1, 16, 12, 40, generator=g)
+    x[0, 3, 5, 7] = float("nan")
+    x[0, 2, 9, 30] = float("inf")
+    x[0, 1, 2, 20] = float("-inf")
+    w = torch.zeros(cout, 16, 3, 3)
+    for c in range(cout):
+        w[c, c % 16, 1, 1] = 1.0 if c % 2 == 0 else -1.0       # centre tap only: no inf - inf inside the sum
+    ref = F.conv2d(x, w, None, 1, 1)
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "lrelu":
+        ref = F.leaky_relu(ref, 0.2)
+    out = ops.conv2d([x.to(dev)], w, None, None, act).cpu()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref))
+    fin = ~torch.isnan(ref)
+    assert torch.equal(out[fin], ref[fin])
+
+
 def test_conv2d_identity_kernel_is_exact(dev):
     """A=I style check with an asymmetric input: centre-tap identity weights must copy x bit-exactly
     (catches transposed fragment layouts that symmetric data would hide)."""
