@@ -81,8 +81,6 @@ enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 // fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
-// experimental wave-specialised variant (hcf_conv_f16x3_ws.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
-int launch_conv_f16x3_ws(const ConvArgs& a, hipStream_t st);
 // split16-source variant staged by LDS-DMA (hcf_conv_f16x3_dma.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
 int launch_conv_f16x3_dma(const ConvArgs& a, hipStream_t st);
 int launch_to_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);

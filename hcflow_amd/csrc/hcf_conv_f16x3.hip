@@ -595,10 +595,6 @@ int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st) {
   for (int i = 0; i < a.nsrc; ++i)
     if ((a.H >> a.src[i].up) << a.src[i].up != a.H || (a.W >> a.src[i].up) << a.src[i].up != a.W) return HCF_ERR_ARG;
   const int nt = (a.out.n + 31) / 32;
-  if (taps == 9 && (g_f16x3_ablation & 16)) {            // tools/conv_bench.py --ablate 16: wave-specialised experiment
-    const int r = launch_conv_f16x3_ws(a, st);
-    if (r != HCF_ERR_UNSUPPORTED) return r;
-  }
   if (taps == 9 && nt == 1) return f16x3::launch_t<1>(a, st);
   if (taps == 9 && nt == 2) return f16x3::launch_t<2>(a, st);
   // 1x1 convs (FCN conv2) and > 64 output channels stay on the exact kernel
