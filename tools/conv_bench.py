@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--precision", default="exact", choices=["exact", "f16x3"])
-    ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0,
+                    help="experiment switches (hcf_debug_set_ablation): 1 / 2 16-row tile for the 32 / 64-channel kernel, "
+                         "32 also run the split16 LDS-DMA kernel and report max |diff| in the clk column "
+                         "(bits << 8: its timing ablations), 64 scalar epilogue")
     args = ap.parse_args()
     lib = _lib.load()
     assert lib.hcf_op_set_precision(_lib.Engine.PRECISIONS[args.precision]) == 0
