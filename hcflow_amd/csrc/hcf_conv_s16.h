@@ -63,7 +63,9 @@ struct Args {
 };
 
 // w: PyTorch [cout][cin][3][3]; cin multiple of 16. Plane 0 = f16(w) * 2^11, plane 1 = f16((w - f16(w)) * 2^11).
-static inline bool pack_weights_s16(const float* w, int cin, int cout, std::vector<uint16_t>& pk) {
+// chunk_major = false: [ntile][chunk] blocks (conv_s16_kernel, one 32-channel tile per unit); true: [chunk][ntile] blocks
+// (conv_s16w_kernel: both tiles of a chunk are one contiguous 36 KB piece).
+static inline bool pack_weights_s16(const float* w, int cin, int cout, std::vector<uint16_t>& pk, bool chunk_major = false) {
   const int nchunk = cin / 16, ntn = (cout + 31) / 32;
   pk.assign(((size_t)ntn * nchunk + 1) * (B_BYTES / 2), 0);      // + one zero chunk: the DMA cursor runs one chunk ahead
   for (int nt = 0; nt < ntn; ++nt)
@@ -78,7 +80,8 @@ static inline bool pack_weights_s16(const float* w, int cin, int cout, std::vect
               if (!(fabsf(x) * 2048.f < 60000.f)) return false;
               const _Float16 hi = (_Float16)x;
               const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((x - (float)hi) * 2048.f);
-              const size_t o = ((size_t)(nt * nchunk + c) * B_BYTES) / 2 + (size_t)((t * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
+              const size_t blk = chunk_major ? (size_t)c * ntn + nt : (size_t)nt * nchunk + c;
+              const size_t o = (blk * B_BYTES) / 2 + (size_t)((t * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
               memcpy(&pk[o], &p0, 2);
               memcpy(&pk[o + 512], &p1, 2);
             }
@@ -486,6 +489,336 @@ static inline int launch(const Args& a, int ncu, hipStream_t st) {
   if (!o16 && o32 && res == 1) return launch_t<true, false, 1>(a, ncu, nunits, st);
   if (!o16 && o32 && res == 2) return launch_t<true, false, 2>(a, ncu, nunits, st);
   if (o16 && o32 && res == 0) return launch_t<true, true, 0>(a, ncu, nunits, st);
+  return -6;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide variant for 64 output channels (RDB conv5): one 512-thread block per CU, unit = 16 rows x 32 px x 64 channels, wave w
+// owns output rows 2 w, 2 w + 1 and BOTH 32-channel tiles (4 accumulators), so every staged activation piece feeds twice
+// the MFMAs of the narrow kernel (45 instead of 98 activation bytes per MFMA) and the weights are shared by 16 rows.
+// LDS: 2 stages x (39 KB activations (18 x 34 records, padded to 39 DMA instructions) + 36 KB weights) + table = 150.5 KB.
+// The epilogue is not deferred (the accumulators already take 64 registers); residuals are prefetched in the last chunk.
+namespace wide_consts {
+constexpr int WTH = 16, WHH = WTH + 2;
+constexpr int WA_REAL = WHH * HWP * 64;               // 39 168
+constexpr int WA_PITCH = 39 * 1024;                  // 39 936: 2 496 pieces = 39 instructions (48 dead lanes read the zero page)
+constexpr int WA_PIECES = WA_REAL / 16;               // 2 448
+constexpr int WB2_BYTES = 2 * B_BYTES;               // 36 864 = 36 instructions
+constexpr int WSTAGE = WA_PITCH + WB2_BYTES;           // 76 800 = 75 instructions
+constexpr int WTAB_OFF = 2 * WSTAGE;                  // [64 bs][64 ms]
+constexpr int WLDS_BYTES = 2 * WSTAGE + 512;          // 154 112
+constexpr int WNSLOT = 10;                           // I = 8 j + wave < 75: j = 9 only for waves 0..2
+}  // namespace wide_consts
+using namespace wide_consts;
+
+template <bool OUT32, bool OUT16, int RES>
+__global__ __launch_bounds__(512, 2) void conv_s16w_kernel(const Args a, const int nunits) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, nchunk = a.nchunk;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + WTH - 1) / WTH;
+  const int plane_b = H * W * 64;
+  const int splanes = __builtin_amdgcn_readfirstlane(a.src_planes);
+
+  // DMA slots: instruction I = 8 j + wave; I < 39 activation pieces, 39 <= I < 75 weight pieces. Waves 0..6: j = 0..4
+  // activation, wave 7: j = 0..3; the rest weights (wave-uniform: no mixed instruction)
+  const int na = (wave == 7) ? 4 : 5;                 // activation slots of this wave
+  int hyx[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int p = (8 * j + wave) * 64 + lane;
+    const int rec = p >> 2, hy = rec / HWP, hx = rec - hy * HWP;
+    hyx[j] = (p < WA_PIECES) ? ((hy << 16) | (hx << 8) | (((p & 3) ^ ((hx >> 2) & 3)) << 4)) : (-256 | ((p & 3) << 4));   // dead lane: zero page
+  }
+  const gcptr srcp = uniform_ptr(a.src + (size_t)a.src_rec0 * plane_b);
+  const gcptr wq = uniform_ptr(a.wpack);
+  const gcptr zpage = uniform_ptr(a.zeros);
+  const int boff = ((8 * 4 + wave) * 64 + lane) * 16 - WA_PITCH;          // weight-stage byte offset of slot 4 seen as a weight slot
+
+  gcptr gp[5], gpb;
+  int ginc[5];
+  int binc = WB2_BYTES;
+  int ub = 0, uy0 = 0, ux0 = 0;
+
+  auto setup_unit = [&](int U) {
+    const int t_ = xcd_remap(U, nunits);
+    ux0 = __builtin_amdgcn_readfirstlane((t_ % tiles_x) * TW);
+    uy0 = __builtin_amdgcn_readfirstlane(((t_ / tiles_x) % tiles_y) * WTH);
+    ub = __builtin_amdgcn_readfirstlane(t_ / (tiles_x * tiles_y));
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int y = uy0 + (hyx[j] >> 16) - 1, x = ux0 + ((hyx[j] >> 8) & 255) - 1, als = hyx[j] & 255;
+      const bool in = hyx[j] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+      gp[j] = in ? srcp + (size_t)ub * splanes * plane_b + (unsigned)((y * W + x) * 64 + als) : zpage + als;
+      ginc[j] = in ? plane_b : 0;
+    }
+    gpb = wq + boff;
+    binc = WB2_BYTES;
+  };
+  auto setup_dead = [&]() {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { gp[j] = zpage + ((lane & 3) << 4); ginc[j] = 0; }
+    gpb = wq + boff;                                   // re-reads the first chunk's weights into a stage nobody reads
+    binc = 0;
+  };
+  // slot J of the next chunk -> stage STG. Weight slots: byte offset (8 (J - 4) * 1024) from slot 4's weight position
+  auto issue_slot = [&](auto jc, int stg) {
+    constexpr int J = decltype(jc)::value;
+    char* const d_ = lds + stg * WSTAGE + (8 * J + wave) * 1024;
+    if (J < 4) { glds16(gp[J < 5 ? J : 0], d_); gp[J < 5 ? J : 0] += ginc[J < 5 ? J : 0]; }
+    else if (J == 4) {
+      if (na == 5) { glds16(gp[4], d_); gp[4] += ginc[4]; }
+      else glds16(gpb, d_);
+    } else if (J < 9) glds16(gpb + (J - 4) * 8192, d_);
+    else { if (wave < 3) glds16(gpb + 5 * 8192, d_); gpb += binc; }
+  };
+#define S16W_ISSUE(J, STG) issue_slot(std::integral_constant<int, (J)>{}, (STG));
+
+  const int wm = wave;
+  int fa_hi[3], fa_lo[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int x = li + dx, key = (x >> 2) & 3;
+    const int rec = (2 * wm) * HWP + x;
+    fa_hi[dx] = rec * 64 + ((half ^ key) << 4);
+    fa_lo[dx] = rec * 64 + (((2 + half) ^ key) << 4);
+  }
+  const int fb = WA_PITCH + half * 512 + li * 16;
+
+  if (tid < 64) {
+    const float sc_ = a.scale[tid], bi_ = a.bias[tid];
+    reinterpret_cast<float*>(lds + WTAB_OFF)[tid] = bi_ * sc_;
+    reinterpret_cast<float*>(lds + WTAB_OFF)[64 + tid] = sc_ * UNSPLIT;
+  }
+
+  int u = blockIdx.x;
+  if (u >= nunits) return;
+  setup_unit(u);
+  S16W_ISSUE(0, 0) S16W_ISSUE(1, 0) S16W_ISSUE(2, 0) S16W_ISSUE(3, 0) S16W_ISSUE(4, 0)
+  S16W_ISSUE(5, 0) S16W_ISSUE(6, 0) S16W_ISSUE(7, 0) S16W_ISSUE(8, 0) S16W_ISSUE(9, 0)
+  int g = 0;
+  const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+  const float alo_ = (slope == 0.f) ? -3.0e38f : -INFINITY;
+
+  f32x16 acc[2][2];                               // [output row][32-channel tile]
+  f32x4 rl1[2][8];                                // residual 1 of this unit (prefetched in its last chunk)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rl1[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one 16-channel chunk; LAST: prefetch this unit's residual 1, point the DMA cursor at the next unit
+  auto do_chunk = [&](auto lastc, const int un, int& eb, int& ey0, int& ex0) {
+    constexpr bool LAST = decltype(lastc)::value;
+    const int stg = g & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (LAST) {
+      eb = ub; ey0 = uy0; ex0 = ux0;
+      if (RES > 0) {
+        const int x = ux0 + li, xc = x < W ? x : W - 1;
+        const int y = uy0 + 2 * wm;                 // row 0 only: row 1's residual is read at the start of the epilogue (registers)
+        const size_t pix = (size_t)((size_t)ub * H + (y < H ? y : H - 1)) * W + xc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          rl1[0][q] = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + 4 * half + 8 * q);
+      }
+      if (un < nunits) setup_unit(un); else setup_dead();
+    }
+    const char* const sb = lds + stg * WSTAGE;
+    const int so = stg ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+#define S16W_W(DX, DY, NT, PL) (*reinterpret_cast<const f16x8*>(sb + fb + (NT) * B_BYTES + ((DY) * 3 + (DX)) * 2048 + (PL) * 1024))
+#define S16W_P(DX, R, PL) (*reinterpret_cast<const f16x8*>(sb + ((PL) ? fa_lo[DX] : fa_hi[DX]) + (R) * (HWP * 64)))
+    f16x8 w00 = S16W_W(0, 0, 0, 0), p0h = S16W_P(0, 0, 0), p1h = S16W_P(0, 1, 0), w10 = S16W_W(0, 0, 1, 0);
+    f16x8 w01 = S16W_W(0, 0, 0, 1), w11 = S16W_W(0, 0, 1, 1), p0l = S16W_P(0, 0, 1), p1l = S16W_P(0, 1, 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      f16x8 n00, n01, n10, n11, nah, nal, nbh, nbl;
+      int nld = 0;
+      if (s < 8) {
+        const int ndx = (s + 1) / 3, ndy = (s + 1) % 3;
+        n00 = S16W_W(ndx, ndy, 0, 0);
+        if (ndy == 0) { nah = S16W_P(ndx, 0, 0); nbh = S16W_P(ndx, 1, 0); }
+        else nbh = S16W_P(ndx, ndy + 1, 0);
+        n10 = S16W_W(ndx, ndy, 1, 0);
+        n01 = S16W_W(ndx, ndy, 0, 1);
+        n11 = S16W_W(ndx, ndy, 1, 1);
+        if (ndy == 0) { nal = S16W_P(ndx, 0, 1); nbl = S16W_P(ndx, 1, 1); nld = 8; }
+        else { nbl = S16W_P(ndx, ndy + 1, 1); nld = 6; }
+      }
+#if !defined(S16_NO_DMA)
+      if (s == 0) { S16W_ISSUE(0, so) S16W_ISSUE(1, so) }
+      if (s == 1) S16W_ISSUE(2, so)
+      if (s == 2) S16W_ISSUE(3, so)
+      if (s == 3) S16W_ISSUE(4, so)
+      if (s == 4) S16W_ISSUE(5, so)
+      if (s == 5) S16W_ISSUE(6, so)
+      if (s == 6) S16W_ISSUE(7, so)
+      if (s == 7) S16W_ISSUE(8, so)
+      if (s == 8) S16W_ISSUE(9, so)
+#endif
+      // 12 MFMAs: (term, tile, row); consecutive ones share the weight fragment and hit different accumulators
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w00, p0h, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w00, p1h, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w10, p0h, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w10, p1h, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w01, p0h, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w01, p1h, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w11, p0h, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w11, p1h, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w00, p0l, acc[0][0], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w00, p1l, acc[1][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w10, p0l, acc[0][1], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w10, p1l, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (k < nld) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#if !defined(S16_NO_DMA)
+        if (k == 8) { if (s == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#endif
+      }
+      if (s < 8) {
+        w00 = n00; w01 = n01; w10 = n10; w11 = n11;
+        if ((s + 1) % 3 == 0) { p0h = nah; p0l = nal; p1h = nbh; p1l = nbl; }
+        else { p0h = p1h; p0l = p1l; p1h = nbh; p1l = nbl; }
+      }
+    }
+#undef S16W_W
+#undef S16W_P
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    ++g;
+  };
+
+  while (true) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int un = u + gridDim.x;
+    int eb = 0, ey0 = 0, ex0 = 0;
+    for (int c = 0; c + 1 < nchunk; ++c) do_chunk(std::false_type{}, un, eb, ey0, ex0);
+    do_chunk(std::true_type{}, un, eb, ey0, ex0);
+    // ---- epilogue: lane (pixel li, k-half `half`) holds channels 32 nt + (r&3) + 8 (r>>2) + 4 half of rows 2 wm, 2 wm + 1 ----
+    {
+      float chk = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][n][r], 0.f, chk);
+      if (__any(chk != chk)) {
+        if (lane == 0) atomicOr(a.ovf, 1);
+      }
+    }
+    const int x = ex0 + li, xc = x < W ? x : W - 1;
+    if (RES >= 1) {
+      const int y = ey0 + 2 * wm + 1;
+      const size_t pix = (size_t)((size_t)eb * H + (y < H ? y : H - 1)) * W + xc;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        rl1[1][q] = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + 4 * half + 8 * q);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int y = ey0 + 2 * wm + m;
+      const bool ok = y < H && x < W;
+      const size_t pix = (size_t)((size_t)eb * H + (y < H ? y : H - 1)) * W + xc;
+      f32x4 r2[8];
+      if (RES == 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r2[q] = *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + 4 * half + 8 * q);
+      }
+#pragma unroll
+      for (int gI = 0; gI < 4; ++gI) {        // 16-channel group: tile gI >> 1, half-tile gI & 1
+        f32x4 v[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * gI + qq;          // float4 unit q: channels 8 q + 4 half .. + 3
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + WTAB_OFF + (8 * q + 4 * half) * 4);
+          const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + WTAB_OFF + 256 + (8 * q + 4 * half) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = fmaf(acc[m][gI >> 1][4 * (q & 3) + e], ms[e], bs[e]);
+            t = act1(t, slope, alo_);
+            if (RES >= 1) t = t * a.rs1 + rl1[m][q][e];
+            if (RES == 2) t = t * a.rs2 + r2[q][e];
+            v[qq][e] = t;
+          }
+        }
+#if !defined(S16_NO_EPI)
+        if (ok) {
+          if (OUT32) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+              *reinterpret_cast<f32x4*>(a.out32 + pix * a.out32_cs + a.out32_c0 + 4 * half + 8 * (2 * gI + qq)) = v[qq];
+          }
+          if (OUT16) {
+            char* const o = a.out16 + ((size_t)eb * a.out16_planes + a.out16_rec0 + gI) * plane_b + (size_t)((y * W + x) * 64 + half * 16);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float t = v[e >> 2][e & 3];
+              hi[e] = (_Float16)t;
+              lo[e] = (_Float16)(t - (float)hi[e]);
+            }
+            *reinterpret_cast<f16x8*>(o) = hi;
+            *reinterpret_cast<f16x8*>(o + 32) = lo;
+          }
+        }
+#else
+        if (ok && v[0][0] == 123.456f) a.out32[0] = v[1][1];
+#endif
+      }
+    }
+    u = un;
+    if (u >= nunits) break;
+  }
+#undef S16W_ISSUE
+}
+
+template <bool OUT32, bool OUT16, int RES>
+static inline int launch_w(const Args& a, int ncu, long long nunits, hipStream_t st) {
+  static bool attr = false;
+  auto fn = conv_s16w_kernel<OUT32, OUT16, RES>;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_BYTES) != hipSuccess) return -2;
+    attr = true;
+  }
+  const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(512), WLDS_BYTES, st, a, (int)nunits);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// 64 output channels, weights packed chunk-major (pack_weights_s16(..., true)); same argument checks as launch()
+static inline int launch_wide(const Args& a, int ncu, hipStream_t st) {
+  if (!a.src || !a.wpack || !a.bias || !a.scale || !a.ovf || !a.zeros || a.nchunk < 1 || a.ntile_n != 2) return -1;
+  if ((reinterpret_cast<uintptr_t>(a.src) & 63) || a.src_rec0 + a.nchunk > a.src_planes) return -1;
+  if (a.out16 && ((reinterpret_cast<uintptr_t>(a.out16) & 63) || a.out16_rec0 + 4 > a.out16_planes)) return -1;
+  if ((long long)a.H * a.W * 64 >= 0x7fffffffLL) return -6;
+  if (a.out32 && (((a.out32_cs | a.out32_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out32) & 15))) return -1;
+  if (a.res1 && (((a.res1_cs | a.res1_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res1) & 15))) return -1;
+  if (a.res2 && (((a.res2_cs | a.res2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res2) & 15))) return -1;
+  if ((a.res2 && !a.res1) || (!a.out16 && !a.out32)) return -1;
+  if ((long long)a.B * a.H * a.W >= 0x7fffffffLL) return -6;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + WTH - 1) / WTH;
+  const long long nunits = (long long)a.B * tiles_x * tiles_y;
+  if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
+  const int res = a.res2 ? 2 : a.res1 ? 1 : 0;
+  const bool o32 = a.out32 != nullptr, o16 = a.out16 != nullptr;
+  if (o16 && o32 && res == 1) return launch_w<true, true, 1>(a, ncu, nunits, st);
+  if (o16 && o32 && res == 2) return launch_w<true, true, 2>(a, ncu, nunits, st);
+  if (o16 && o32 && res == 0) return launch_w<true, true, 0>(a, ncu, nunits, st);
+  if (!o16 && o32 && res == 0) return launch_w<true, false, 0>(a, ncu, nunits, st);
+  if (!o16 && o32 && res == 1) return launch_w<true, false, 1>(a, ncu, nunits, st);
+  if (o16 && !o32 && res == 0) return launch_w<false, true, 0>(a, ncu, nunits, st);
   return -6;
 }
 #endif  // __HIPCC__

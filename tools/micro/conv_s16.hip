@@ -93,6 +93,7 @@ int main(int argc, char** argv) {
       {"check small 64->32  lrelu  s16 out", 2, 24, 40, 64, 32, 2, false, true, false},
       {"check small 192->64 res    f32+s16", 1, 17, 70, 192, 64, 0, true, true, true},
       {"check small 96->32  relu   f32 out", 1, 8, 32, 96, 32, 1, false, false, true},
+      {"check small 64->64  lrelu  f32+s16", 2, 40, 70, 64, 64, 2, false, true, true},
       {"rdb conv1 L0  64->32  @320", 16, 320, 320, 64, 32, 2, false, true, false},
       {"rdb conv2 L0  96->32  @320", 16, 320, 320, 96, 32, 2, false, true, false},
       {"rdb conv4 L0 160->32  @320", 16, 320, 320, 160, 32, 2, false, true, false},
@@ -122,7 +123,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < w.size(); ++i) w[i] = hashf(i, 3) * 0.5f / sqrtf((float)P.cin * 9.f);
     for (int i = 0; i < P.cout; ++i) { bias[i] = hashf(i, 5) * 0.1f; scale[i] = 1.f + 0.1f * hashf(i, 6); }
     std::vector<uint16_t> pk;
-    if (!pack_weights_s16(w.data(), P.cin, P.cout, pk)) { printf("pack failed\n"); return 1; }
+    const bool wide = (variant & 1) && P.cout == 64;
+    if (!pack_weights_s16(w.data(), P.cin, P.cout, pk, wide)) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
@@ -136,7 +138,8 @@ int main(int argc, char** argv) {
     if (P.res) { a.res1 = res; a.res1_cs = 64; a.res1_c0 = 0; a.rs1 = 0.2f; }
     a.variant = variant;
     unsigned long long* dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); a.dbg = dbg;
-    int rc = launch(a, ncu, 0);
+    auto launch_any = [&](const Args& aa) { return wide ? launch_wide(aa, ncu, 0) : launch(aa, ncu, 0); };
+    int rc = launch_any(a);
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -165,9 +168,9 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) launch(a, ncu, 0);
+      for (int i = 0; i < 2; ++i) launch_any(a);
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) launch(a, ncu, 0);
+      for (int i = 0; i < iters; ++i) launch_any(a);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * P.cin * P.cout * (double)npix;
