@@ -55,16 +55,46 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     if (threadIdx.x < n) {
       float t0 = 0.f, t1 = 0.f;
       for (int g = 0; g < groups; ++g) { t0 += sh[0][g * n + threadIdx.x]; t1 += sh[1][g * n + threadIdx.x]; }
-      if (a.sum_pre) atomicAdd(a.sum_pre + threadIdx.x, t0);
-      if (a.sum_zy) atomicAdd(a.sum_zy + threadIdx.x, t1 * a.zy_mult);
+      if (a.part) {                                  // fixed-order reduction later (launch_sum_jobs)
+        a.part[((size_t)blockIdx.x * 2 + 0) * n + threadIdx.x] = t0;
+        a.part[((size_t)blockIdx.x * 2 + 1) * n + threadIdx.x] = t1;
+      } else {
+        if (a.sum_pre) atomicAdd(a.sum_pre + threadIdx.x, t0);
+        if (a.sum_zy) atomicAdd(a.sum_zy + threadIdx.x, t1 * a.zy_mult);
+      }
     }
   }
+}
+
+constexpr int kEpiBwdPixelsPerBlock = 96;    // >= 1000 blocks for a 16 x 80 x 80 tensor
+int conv_epilogue_bwd_blocks(int B, int H, int W) {
+  const long long npix = (long long)B * H * W;
+  return (int)((npix + kEpiBwdPixelsPerBlock - 1) / kEpiBwdPixelsPerBlock);
+}
+
+__global__ __launch_bounds__(256) void sum_jobs_kernel(const SumJob* jobs) {
+  const SumJob j = jobs[blockIdx.x];
+  for (int t = threadIdx.x; t < 2 * j.n; t += 256) {
+    const int which = t / j.n, c = t - which * j.n;
+    float* const dst = which ? j.dst1 : j.dst0;
+    if (!dst) continue;
+    const float* p = j.part + (size_t)which * j.pstride + c;
+    double s = 0.0;
+    for (int b = 0; b < j.nblk; ++b) s += (double)p[(size_t)b * 2 * j.pstride];
+    dst[c] += (float)(which ? s * (double)j.mult1 : s);
+  }
+}
+
+int launch_sum_jobs(const SumJob* jobs_dev, int njobs, hipStream_t st) {
+  if (njobs <= 0) return HCF_OK;
+  hipLaunchKernelGGL(sum_jobs_kernel, dim3((unsigned)njobs), dim3(256), 0, st, jobs_dev);
+  HCF_RET_T();
 }
 
 int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st) {
   if (a.gy.n < 1 || a.gy.n > 256 || a.gpre.n != a.gy.n) return HCF_ERR_ARG;
   const long long npix = (long long)a.B * a.H * a.W;
-  const int ppb = 96;          // >= 1000 blocks for a 16 x 80 x 80 tensor; one atomic per channel per block
+  const int ppb = kEpiBwdPixelsPerBlock;
   hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, st, a, npix, ppb);
   HCF_RET_T();
 }
@@ -106,11 +136,42 @@ int launch_step_couple_bwd(const StepBwdArgs& a, hipStream_t st) {
 }
 
 // ---- head backward: zb = W za, za = (zin + b) e^s  ->  gza = W^T gzb, gzin = gza e^s, sums for b and s -----------
+// per-channel block sums in a fixed order: wave shuffle tree, then the four wave results added in wave order
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+template <int CMAX>
+__device__ __forceinline__ void block_channel_sums(const float (&v0)[CMAX], const float (&v1)[CMAX], int C, float (*shw)[2][CMAX],
+                                                   float* g0, float* g1, float* part, int blk) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const float s0 = wave_sum_t(v0[c]), s1 = wave_sum_t(v1[c]);
+    if (lane == 0) { shw[w][0][c] = s0; shw[w][1][c] = s1; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    const float t0 = ((shw[0][0][c] + shw[1][0][c]) + shw[2][0][c]) + shw[3][0][c];
+    const float t1 = ((shw[0][1][c] + shw[1][1][c]) + shw[2][1][c]) + shw[3][1][c];
+    if (part) {
+      part[((size_t)blk * 2 + 0) * CMAX + c] = t0;
+      part[((size_t)blk * 2 + 1) * CMAX + c] = t1;
+    } else {
+      atomicAdd(g0 + c, t0);
+      atomicAdd(g1 + c, t1);
+    }
+  }
+}
+
 template <int CMAX>
 __global__ __launch_bounds__(256) void step_head_bwd_kernel(const StepBwdArgs a) {
-  __shared__ float sh[2][CMAX];
-  if (threadIdx.x < CMAX) { sh[0][threadIdx.x] = 0.f; sh[1][threadIdx.x] = 0.f; }
-  __syncthreads();
+  __shared__ float shw[4][2][CMAX];
+  float v0[CMAX], v1[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { v0[c] = 0.f; v1[c] = 0.f; }
   const int hw = a.H * a.W;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < hw) {
@@ -130,17 +191,13 @@ __global__ __launch_bounds__(256) void step_head_bwd_kernel(const StepBwdArgs a)
     for (int c = 0; c < CMAX; ++c) {
       gin[c] = gza[c] * mul[c];
       if (c < a.C) {
-        atomicAdd(&sh[0][c], gin[c]);              // d bias  = sum gza e^s
-        atomicAdd(&sh[1][c], gza[c] * za[c]);      // d logs  = sum gza * za
+        v0[c] = gin[c];                            // d bias  = sum gza e^s
+        v1[c] = gza[c] * za[c];                    // d logs  = sum gza * za
       }
     }
     store_pixel<CMAX>(a.gzin, pix, a.C, gin);
   }
-  __syncthreads();
-  if (threadIdx.x < a.C) {
-    atomicAdd(a.g_bias + threadIdx.x, sh[0][threadIdx.x]);
-    atomicAdd(a.g_logs + threadIdx.x, sh[1][threadIdx.x]);
-  }
+  block_channel_sums<CMAX>(v0, v1, a.C, shw, a.g_bias, a.g_logs, a.part, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 int launch_step_head_bwd(const StepBwdArgs& a, hipStream_t st) {
@@ -204,9 +261,10 @@ int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, i
 // ---- inverse flow step backward (one thread per pixel) ---------------------------------------------------------------
 template <int CMAX>
 __global__ __launch_bounds__(256) void step_inv_bwd_kernel(const StepInvBwdArgs a) {
-  __shared__ float sh[2][CMAX];
-  if (threadIdx.x < CMAX) { sh[0][threadIdx.x] = 0.f; sh[1][threadIdx.x] = 0.f; }
-  __syncthreads();
+  __shared__ float shw[4][2][CMAX];
+  float v0[CMAX], v1[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { v0[c] = 0.f; v1[c] = 0.f; }
   const int hw = a.H * a.W;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < hw) {
@@ -221,8 +279,8 @@ __global__ __launch_bounds__(256) void step_inv_bwd_kernel(const StepInvBwdArgs 
       y[c] = xb * mf[c];
       gy[c] = gx[c] * mi[c];
       if (c < a.C) {
-        atomicAdd(&sh[0][c], -gx[c]);               // x = y e^-s - b
-        atomicAdd(&sh[1][c], -gx[c] * xb);
+        v0[c] = -gx[c];                             // x = y e^-s - b
+        v1[c] = -gx[c] * xb;
       }
     }
     if (a.matInvT) {
@@ -255,11 +313,7 @@ __global__ __launch_bounds__(256) void step_inv_bwd_kernel(const StepInvBwdArgs 
       for (int c = 0; c < 3; ++c) oh[c] = -gzc[c];                  // z[:3] -= h
     store_pixel<CMAX>(a.gz, pix, a.C, gz);
   }
-  __syncthreads();
-  if (threadIdx.x < a.C) {
-    atomicAdd(a.g_bias + threadIdx.x, sh[0][threadIdx.x]);
-    atomicAdd(a.g_logs + threadIdx.x, sh[1][threadIdx.x]);
-  }
+  block_channel_sums<CMAX>(v0, v1, a.C, shw, a.g_bias, a.g_logs, a.part, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 int launch_step_inv_bwd(const StepInvBwdArgs& a, hipStream_t st) {
