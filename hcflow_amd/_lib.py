@@ -15,11 +15,14 @@ HCF_OK = 0
 ERR_NAMES = {-1: "HCF_ERR_ARG", -2: "HCF_ERR_HIP", -3: "HCF_ERR_STATE", -4: "HCF_ERR_KEY",
              -5: "HCF_ERR_SHAPE", -6: "HCF_ERR_UNSUPPORTED", -7: "HCF_ERR_NOMEM"}
 FLAG_NO_CLAMP = 1
+FLAG_NO_RANGE_CHECK = 2
+FLAG_KEEP_COND = 4
+FLAG_REUSE_COND = 8
 
 # every symbol include/hcflow.h declares (tests/test_cabi_cpu.py checks the .so exports them all)
 SYMBOLS = [
     "hcf_create", "hcf_destroy", "hcf_last_error", "hcf_param_count", "hcf_param_info",
-    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_forward_sr", "hcf_forward_rescale",
+    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_inverse_ex", "hcf_check_range", "hcf_forward_sr", "hcf_forward_rescale",
     "hcf_workspace_bytes", "hcf_weight_bytes", "hcf_profile_convs", "hcf_conv_time_ms",
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
@@ -71,6 +74,8 @@ def load() -> C.CDLL:
     lib.hcf_set_param.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
     lib.hcf_finalize.argtypes = [vp, C.c_int]
     lib.hcf_inverse.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, fp, i32, i32, i32, u32, vp]
+    lib.hcf_inverse_ex.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, i64, fp, i32, i32, i32, u32, vp]
+    lib.hcf_check_range.argtypes = [vp, C.POINTER(i32)]
     lib.hcf_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.hcf_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, u32, vp]
     lib.hcf_workspace_bytes.argtypes = [vp]
@@ -226,6 +231,13 @@ class Engine:
 
     def fallback_count(self) -> int:
         return int(self.lib.hcf_fallback_count(self._h))
+
+    def check_range(self) -> bool:
+        """True when an f16x3 pass since the last check saw an input beyond the f16 range (include/hcflow.h: hcf_check_range).
+        Waits for the passes enqueued so far."""
+        o = C.c_int32(0)
+        check(self.lib.hcf_check_range(self._h, C.byref(o)), self._h, "hcf_check_range")
+        return bool(o.value)
 
     def profile_convs(self, enable: bool):
         check(self.lib.hcf_profile_convs(self._h, int(enable)), self._h, "hcf_profile_convs")

@@ -383,12 +383,60 @@ class _EngineModule(nn.Module):
         spec = [(k, tuple(s)) for k, s, _ in param_spec(self.cfg)]
         have = [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
         assert have == spec, "internal: module tree does not match the reference state_dict table"
+        object.__setattr__(self, "_spec_keys", [k for k, _ in spec])
         # engines are per device (nn.DataParallel replicas share this dict but not the entries)
         object.__setattr__(self, "_engines", {})
-        # conv numerics: "exact" unless HCFLOW_PRECISION=f16x3 is set (lets the unmodified reference scripts opt in)
-        default_prec = os.environ.get("HCFLOW_PRECISION", "exact")
+        # conv numerics. Default "f16x3": fp32-equivalent split products on the f16 matrix cores with fp32 accumulation
+        # (deviation from an fp64 evaluation of the full nets equals plain fp32's; inputs beyond the f16 range
+        # are detected and the pass is re-run exactly). HCFLOW_PRECISION=exact (or set_precision("exact")) selects the fp32
+        # MFMA kernels, a bit-exact fp32 fma chain at 1/3 of the throughput.
+        default_prec = os.environ.get("HCFLOW_PRECISION", "f16x3")
         assert default_prec in _lib.Engine.PRECISIONS, "HCFLOW_PRECISION must be one of %s" % list(_lib.Engine.PRECISIONS)
         object.__setattr__(self, "_precision", [default_prec])
+        # f16x3 range check: "sync" (default) asks the engine after every pass and re-runs an overflowed pass exactly
+        # (one host-device synchronisation per call, here in Python, never inside the C ABI); "lazy" leaves it to
+        # check_range() (the calls only enqueue: CUDA-graph capturable); "off" skips the read-back altogether.
+        object.__setattr__(self, "_range_check", [os.environ.get("HCFLOW_RANGE_CHECK", "sync")])
+        object.__setattr__(self, "_cond_key", {})
+
+    def set_range_check(self, mode: str):
+        assert mode in ("sync", "lazy", "off"), mode
+        self._range_check[0] = mode
+        return self
+
+    def check_range(self) -> bool:
+        """"lazy" mode: True if an f16x3 pass since the last check overflowed the f16 range (its outputs are invalid and
+        must be recomputed with set_precision("exact")). Waits for the enqueued passes."""
+        return any(ent["engine"].check_range() for ent in self._engines.values())
+
+    def invalidate(self):
+        """Force a repack of every engine on its next call. Needed after writes the version counters do not see
+        (``p.data.copy_()`` / ``p.data.mul_()`` as EMA or clipping code does): the engine otherwise keeps its packed
+        weights, inverse matrices and log-det constants. Also re-arms the "ActNorm already fitted" bookkeeping."""
+        for ent in self._engines.values():
+            ent["stamp"] = None
+            ent["ptrs"] = None
+        for m in self.modules():
+            if isinstance(m, ActNorm2d) and hasattr(m, "_hcf_fitted"):
+                del m._hcf_fitted
+        self._cond_key.clear()
+        return self
+
+    def _tensors(self):
+        """[(key, tensor)] in state_dict order, resolved through the ATTRIBUTE tree: nn.DataParallel replicas carry their
+        parameters as plain tensor attributes (torch >= 1.5: replica.parameters() is empty), and those tensors are the
+        ones autograd must see so that gradients flow back to the wrapped module (HCFlow_SR_model.py:33-36)."""
+        out = []
+        for key in self._spec_keys:
+            obj = self
+            path = key.split(".")
+            for a in path[:-1]:
+                obj = getattr(obj, a)
+            out.append((key, getattr(obj, path[-1])))
+        return out
+
+    def _device(self):
+        return self._tensors()[0][1].device
 
     def set_precision(self, mode: str):
         """"exact": fp32 MFMA convolutions (default). "f16x3": fp32-equivalent split products on the
@@ -411,10 +459,11 @@ class _EngineModule(nn.Module):
             ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
             ent["engine"].set_precision(self._precision[0])
             self._engines[idx] = ent
-        stamp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        named = self._tensors()
+        stamp = tuple((p.data_ptr(), p._version) for _, p in named)
         if ent["stamp"] != stamp:
             eng = ent["engine"]
-            named = list(self.named_parameters())
+            self._cond_key.pop(idx, None)
             ptrs = tuple(p.data_ptr() for _, p in named)
             on_dev = all(p.device.type == "cuda" and p.device.index == idx and p.dtype == torch.float32 and p.is_contiguous()
                          for _, p in named)
@@ -431,8 +480,7 @@ class _EngineModule(nn.Module):
                     eng.refresh_from_device(self._stream(idx))
                 ent["ptrs"] = ptrs
             else:
-                sd = self.state_dict()
-                for key, t in sd.items():
+                for key, t in named:
                     eng.set_param(key, t.detach().to("cpu", torch.float32).contiguous())
                 eng.finalize(idx)
                 ent["ptrs"] = None
@@ -444,7 +492,21 @@ class _EngineModule(nn.Module):
         return ent["engine"], idx
 
     def _wants_grad(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return torch.is_grad_enabled() and any(p.requires_grad for _, p in self._tensors())
+
+    def _params(self):
+        return [p for _, p in self._tensors()]
+
+    def _run_checked(self, eng, idx, call, what):
+        """One inference pass through the C ABI (``call()`` enqueues it and returns the status) under the range-check policy."""
+        with torch.cuda.device(idx):
+            _lib.check(call(), eng.handle, what)
+            if self._precision[0] == "f16x3" and self._range_check[0] == "sync" and eng.check_range():
+                eng.set_precision("exact")                   # an activation left the f16 range: redo this pass exactly
+                try:
+                    _lib.check(call(), eng.handle, what + " (exact re-run)")
+                finally:
+                    eng.set_precision(self._precision[0])
 
     def _check_inference(self, reverse=False):
         if self._wants_grad():
@@ -459,7 +521,27 @@ class _EngineModule(nn.Module):
 
     # -- ActNorm data-dependent initialisation (ActNorms.py:29-43): fitted by the engine during ONE forward pass
     def _pending_actnorms(self):
-        return [(k, m) for k, m in self.named_modules() if isinstance(m, ActNorm2d) and not m.inited]
+        """ActNorms the next train()-mode forward pass has to fit. The reference re-arms ``inited = False`` on every step
+        below act_norm_start_step and relies on each layer's ``(bias != 0).any()`` short-circuit (ActNorms.py:33-35,
+        HCFlow_SR_model.py:462-465); layers already fitted (or found non-zero, one fused device check) are dropped here
+        without an extra statistics pass."""
+        pend = [(k, m) for k, m in self.named_modules() if isinstance(m, ActNorm2d) and not m.inited]
+        if not pend:
+            return pend
+        unknown = [(k, m) for k, m in pend if not getattr(m, "_hcf_fitted", False)]
+        if unknown and all(m.bias.device.type == "cuda" for _, m in unknown):
+            with torch.no_grad():
+                nz = (torch.stack([m.bias.detach().abs().max() for _, m in unknown]) > 0).cpu()
+            for (k, m), f in zip(unknown, nz.tolist()):
+                if f:
+                    m._hcf_fitted = True
+        out = []
+        for k, m in pend:
+            if getattr(m, "_hcf_fitted", False):
+                m.inited = True
+            else:
+                out.append((k, m))
+        return out
 
     def _arm_actnorm_init(self, eng):
         """train() mode and ``inited == False`` -> the next forward pass fits bias / logs (eval() mode never
@@ -478,8 +560,33 @@ class _EngineModule(nn.Module):
                 m.bias.copy_(eng.get_param(k + ".bias", n).view_as(m.bias))
                 m.logs.copy_(eng.get_param(k + ".logs", n).view_as(m.logs))
                 m.inited = True
-        # the engine already holds these values: no repack on the next call
-        self._engines[idx]["stamp"] = tuple((p.data_ptr(), p._version) for p in self.parameters())
+                m._hcf_fitted = True
+        self._broadcast_actnorms(pend)
+        # the engine already holds these values: no repack on the next call (unless the broadcast changed them)
+        if not self._dist_on():
+            self._engines[idx]["stamp"] = tuple((p.data_ptr(), p._version) for _, p in self._tensors())
+
+    @staticmethod
+    def _dist_on():
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _broadcast_actnorms(self, pend):
+        """Under DDP every rank fits its ActNorms to ITS shard (ActNorms.py:28-44 uses local statistics, so the reference
+        starts N ranks from N different parameter sets and DDP never re-synchronises them): rank 0's fit is broadcast, in one
+        flat tensor, so all replicas start equal."""
+        if not pend or not self._dist_on():
+            return
+        import torch.distributed as dist
+        with torch.no_grad():
+            flat = torch.cat([t.detach().reshape(-1) for _, m in pend for t in (m.bias, m.logs)])
+            dist.broadcast(flat, src=0)
+            off = 0
+            for _, m in pend:
+                for t in (m.bias, m.logs):
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
 
     @staticmethod
     def _prep(t: torch.Tensor, device) -> torch.Tensor:
@@ -489,21 +596,25 @@ class _EngineModule(nn.Module):
     def _stream(idx):
         return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
-    def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None):
+    def _inverse(self, lr, eps_std, eps=None, clamp=True, seed=None, sample_offset=0, cache_cond=False):
+        """``sample_offset``: this call is samples [offset, offset + B) of a larger (sharded) batch: the device draws are
+        those of the global samples (hcf_inverse_ex). ``cache_cond``: keep / reuse the deepest level's conditional features
+        while ``lr`` (same tensor, unchanged) and the parameters stay the same (tau sweeps, repeated sampling)."""
         if self._wants_grad() or (torch.is_grad_enabled() and torch.is_tensor(lr) and lr.requires_grad):
             if self.training and self._pending_actnorms():
                 raise NotImplementedError(
                     "un-initialised ActNorm layers in train() mode on the REVERSE path: run one forward (hr -> z) pass "
                     "first, load a checkpoint / set .inited = True, or call .eval().")
-            dev = next(self.parameters()).device
+            dev = self._device()
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             tau = 0.0 if eps_std is None else float(eps_std)
             lr_t = lr.to(device=dev, dtype=torch.float32).contiguous()          # keeps the autograd link to the caller's lr
-            return _SRReverseStep.apply(self, lr_t, tau, seed, bool(clamp), eps, *list(self.parameters()))
+            return _SRReverseStep.apply(self, lr_t, tau, seed, bool(clamp), eps, *self._params())
         self._check_inference(reverse=True)
-        dev = next(self.parameters()).device
+        dev = self._device()
         eng, idx = self._engine_for(dev)
+        lr_in = lr
         lr = self._prep(lr, dev)
         B, c, h, w = lr.shape
         assert c == 3
@@ -525,16 +636,26 @@ class _EngineModule(nn.Module):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
         tau = 0.0 if eps_std is None else float(eps_std)
-        with torch.cuda.device(idx):
-            rc = eng.lib.hcf_inverse(eng.handle, lr.data_ptr(), arr, len(shapes), tau, seed, out.data_ptr(),
-                                     B, h, w, 0 if clamp else _lib.FLAG_NO_CLAMP, self._stream(idx))
-        _lib.check(rc, eng.handle, "hcf_inverse")
+        flags = 0 if clamp else _lib.FLAG_NO_CLAMP
+        if self._range_check[0] == "off":
+            flags |= _lib.FLAG_NO_RANGE_CHECK
+        if cache_cond:
+            # the caller's tensor identity + version stand for its contents; any parameter change drops the key (_engine_for)
+            key = (lr_in.data_ptr(), lr_in._version, tuple(lr_in.shape), str(lr_in.dtype), str(lr_in.device))
+            flags |= _lib.FLAG_REUSE_COND if self._cond_key.get(idx) == key else _lib.FLAG_KEEP_COND
+            self._cond_key[idx] = key
+            keep.append(lr_in)
+        else:
+            self._cond_key.pop(idx, None)
+        stream = self._stream(idx)
+        self._run_checked(eng, idx, lambda: eng.lib.hcf_inverse_ex(
+            eng.handle, lr.data_ptr(), arr, len(shapes), tau, seed, int(sample_offset), out.data_ptr(), B, h, w, flags,
+            stream), "hcf_inverse")
         return out
 
     # convenience for benchmarks / multi-GPU sharding
     def engine(self):
-        dev = next(self.parameters()).device
-        return self._engine_for(dev)[0]
+        return self._engine_for(self._device())[0]
 
 
 class HCFlowNet_SR(_EngineModule):
@@ -548,10 +669,12 @@ class HCFlowNet_SR(_EngineModule):
 
     # hr: HR image, lr: LR image, z: latent variable, u: conditional variable
     def forward(self, hr=None, lr=None, z=None, u=None, eps_std=None,
-                add_gt_noise=False, step=None, reverse=False, training=True, eps=None, noise=None):
+                add_gt_noise=False, step=None, reverse=False, training=True, eps=None, noise=None, seed=None,
+                sample_offset=0, cache_cond=False):
         if not reverse:
             return self.normal_flow_diracLR(hr, lr, u, step=step, training=training, noise=noise)
-        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps)
+        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps, seed=seed,
+                                         sample_offset=sample_offset, cache_cond=cache_cond)
 
     def normal_flow_diracLR(self, hr, lr, u=None, step=None, training=True, noise=None, return_internals=False):
         """hr -> (clamp(LR^), nll)   (HCFlowNet_SR_arch.py:47-67). ``noise``: optional injected U[0,1)
@@ -560,8 +683,9 @@ class HCFlowNet_SR(_EngineModule):
         if self._wants_grad() and not return_internals:
             return self._normal_flow_train(hr, lr, noise)
         self._check_inference()
-        dev = next(self.parameters()).device
+        dev = self._device()
         eng, idx = self._engine_for(dev)
+        self._cond_key.pop(idx, None)
         hr = self._prep(hr, dev)
         B, c, H, W = hr.shape
         s = self.cfg.scale
@@ -575,18 +699,17 @@ class HCFlowNet_SR(_EngineModule):
         logdet = torch.empty(B, device=dev)
         zraw = torch.empty(B, 3, H // s, W // s, device=dev) if return_internals else None
         pend = self._arm_actnorm_init(eng)
-        with torch.cuda.device(idx):
-            rc = eng.lib.hcf_forward_sr(eng.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(),
-                                        noise.data_ptr(), out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(),
-                                        None if zraw is None else zraw.data_ptr(), B, H, W, self._stream(idx))
-        _lib.check(rc, eng.handle, "hcf_forward_sr")
+        stream = self._stream(idx)
+        self._run_checked(eng, idx, lambda: eng.lib.hcf_forward_sr(
+            eng.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(), noise.data_ptr(), out_lr.data_ptr(),
+            nll.data_ptr(), logdet.data_ptr(), None if zraw is None else zraw.data_ptr(), B, H, W, stream), "hcf_forward_sr")
         self._finish_actnorm_init(eng, idx, pend)
         if return_internals:
             return out_lr, nll[0], logdet, zraw
         return out_lr, nll[0]
 
     def _normal_flow_train(self, hr, lr, noise):
-        dev = next(self.parameters()).device
+        dev = self._device()
         assert lr is not None, "the NLL objective needs lr"
         hr, lr = self._prep(hr, dev), self._prep(lr, dev)
         if noise is None:
@@ -597,12 +720,13 @@ class HCFlowNet_SR(_EngineModule):
             # that with one statistics pass on the same batch / noise, then run the differentiable pass
             with torch.no_grad():
                 self.normal_flow_diracLR(hr, lr, noise=noise)
-        out_lr, nll, _ = _SRNLLStep.apply(self, hr, lr, noise, *list(self.parameters()))
+        out_lr, nll, _ = _SRNLLStep.apply(self, hr, lr, noise, *self._params())
         return out_lr, nll
 
-    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):
+    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True, seed=None, sample_offset=0,
+                             cache_cond=False):
         """lr (+ sampled z) -> clamp(HR)   (HCFlowNet_SR_arch.py:70-75)."""
-        return self._inverse(lr, eps_std, eps=eps, clamp=clamp)
+        return self._inverse(lr, eps_std, eps=eps, clamp=clamp, seed=seed, sample_offset=sample_offset, cache_cond=cache_cond)
 
 
 class HCFlowNet_Rescaling(_EngineModule):
@@ -615,22 +739,25 @@ class HCFlowNet_Rescaling(_EngineModule):
         assert not self.cfg.sr
 
     def forward(self, hr=None, lr=None, z=None, u=None, eps_std=None,
-                add_gt_noise=False, step=None, reverse=False, training=True, eps=None):
+                add_gt_noise=False, step=None, reverse=False, training=True, eps=None, seed=None, sample_offset=0,
+                cache_cond=False):
         if not reverse:
             return self.normal_flow_diracLR(hr, lr, u, step=step, training=training)
-        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps)
+        return self.reverse_flow_diracLR(lr, z, u, eps_std=eps_std, training=training, eps=eps, seed=seed,
+                                         sample_offset=sample_offset, cache_cond=cache_cond)
 
     def normal_flow_diracLR(self, hr, lr=None, u=None, step=None, training=True, clamp=True):
         """hr -> (clamp(LR^), z1, z2)   (HCFlowNet_Rescaling_arch.py:39-46)."""
         if self._wants_grad():
-            dev = next(self.parameters()).device
+            dev = self._device()
             if self.training and self._pending_actnorms():
                 with torch.no_grad():                       # fit the ActNorms on this batch first (ActNorms.py:78-80)
                     self.normal_flow_diracLR(hr)
-            return _RescaleForwardStep.apply(self, self._prep(hr, dev), bool(clamp), *list(self.parameters()))
+            return _RescaleForwardStep.apply(self, self._prep(hr, dev), bool(clamp), *self._params())
         self._check_inference()
-        dev = next(self.parameters()).device
+        dev = self._device()
         eng, idx = self._engine_for(dev)
+        self._cond_key.pop(idx, None)
         hr = self._prep(hr, dev)
         B, c, H, W = hr.shape
         assert H % 4 == 0 and W % 4 == 0, "{}".format((H, W, 2))
@@ -641,16 +768,18 @@ class HCFlowNet_Rescaling(_EngineModule):
         z1 = torch.empty(B, c0, H // 2, W // 2, device=dev)
         z2 = torch.empty(B, c1, H // 4, W // 4, device=dev)
         pend = self._arm_actnorm_init(eng)
-        with torch.cuda.device(idx):
-            rc = eng.lib.hcf_forward_rescale(eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(),
-                                             B, H, W, 0 if clamp else _lib.FLAG_NO_CLAMP, self._stream(idx))
-        _lib.check(rc, eng.handle, "hcf_forward_rescale")
+        stream = self._stream(idx)
+        fl = (0 if clamp else _lib.FLAG_NO_CLAMP) | (_lib.FLAG_NO_RANGE_CHECK if self._range_check[0] == "off" else 0)
+        self._run_checked(eng, idx, lambda: eng.lib.hcf_forward_rescale(
+            eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(), B, H, W, fl, stream),
+            "hcf_forward_rescale")
         self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 
-    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True):
+    def reverse_flow_diracLR(self, lr, z, u, eps_std, training=True, eps=None, clamp=True, seed=None, sample_offset=0,
+                             cache_cond=False):
         """lr (+ sampled z) -> clamp(HR)   (HCFlowNet_Rescaling_arch.py:49-54)."""
-        return self._inverse(lr, eps_std, eps=eps, clamp=clamp)
+        return self._inverse(lr, eps_std, eps=eps, clamp=clamp, seed=seed, sample_offset=sample_offset, cache_cond=cache_cond)
 
     def get_score(self, disc_loss_sigma, z):
         """HCFlowNet_Rescaling.get_score (:57-60), unused by every config; kept for API parity."""

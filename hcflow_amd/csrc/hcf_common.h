@@ -170,8 +170,16 @@ struct EpiBwdArgs {
   float* sum_zy;           // nullable
   float zy_mult;
   float* absmax;           // nullable: max |gpre| as float bits (atomicMax on the int view; zero-initialised)
+  float* part;             // per-block partial sums [conv_epilogue_bwd_blocks()][2][gy.n] (sum_pre, sum_zy): reduced in a fixed
+                           // order by launch_sum_jobs, so parameter gradients are bit-reproducible; nullptr: fp32 atomics into sum_*
 };
 int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st);
+int conv_epilogue_bwd_blocks(int B, int H, int W);
+
+// Fixed-order reduction of per-block partial sums into parameter gradients: dst0[c] += sum_b part[b][0][c],
+// dst1[c] += mult1 * sum_b part[b][1][c] (double accumulation, blocks in index order); one block per job.
+struct SumJob { const float* part; int nblk, n, pstride; float* dst0; float* dst1; float mult1; };
+int launch_sum_jobs(const SumJob* jobs_dev, int njobs, hipStream_t st);
 
 struct StepBwdArgs {
   int B, H, W, C, ns, mode;
@@ -184,6 +192,7 @@ struct StepBwdArgs {
   const float* an_mul;     // exp(logs)
   float* g_bias;           // [C] +=
   float* g_logs;           // [C] +=
+  float* part;             // per-block partials [B * step_blocks_per_sample][2][step_cmax(C)] (bias, logs) or nullptr (atomics)
 };
 int launch_step_couple_bwd(const StepBwdArgs& a, hipStream_t st);
 int launch_step_head_bwd(const StepBwdArgs& a, hipStream_t st);
@@ -201,6 +210,7 @@ struct StepInvBwdArgs {
   const float* mul_inv;        // e^-s
   float* g_bias;               // [C] +=
   float* g_logs;               // [C] +=
+  float* part;                 // as StepBwdArgs::part
 };
 int launch_step_inv_bwd(const StepInvBwdArgs& a, hipStream_t st);
 int launch_mask_unit_range(View z, View g, int B, int H, int W, hipStream_t st);      // g = (0 <= z <= 1) ? g : 0
@@ -235,6 +245,7 @@ struct GaussArgs {
   // sample
   const float* eps;      // NCHW [B,C,H,W] already N(0,tau) (injected), or nullptr -> device Philox
   float tau; uint64_t seed; uint64_t offset;
+  int64_t b0;            // device draws: sample b of this call is sample b0 + b of the (sharded) batch, so shards reproduce the full batch
   View out;              // sample: latent out.  logp/encode: latent in
   float* aux;            // encode (rescale fwd): NCHW output z = (a-mean) exp(-logs)
   float* partial; int partial_stride;

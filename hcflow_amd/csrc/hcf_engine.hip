@@ -890,11 +890,18 @@ struct hcf_engine {
 
   // ---------------------------------------------------------------- inverse pass
   // FlowNet.reverse_flow (FlowNet_SR_x4.py:106-123, FlowNet_SR_x8.py:121-144, FlowNet_Rescaling_x4.py:111-128)
-  void pass_inverse(const float* lr, const float* const* eps, int n_eps, float tau, uint64_t seed, float* out, int B,
-                    int h, int w, uint32_t flags) {
+  void pass_inverse(const float* lr, const float* const* eps, int n_eps, float tau, uint64_t seed, int64_t sample0, float* out,
+                    int B, int h, int w, uint32_t flags) {
     B_ = B;
     arena.top = 0;
     const int L = cfg.L;
+    // HCF_FLAG_KEEP_COND / HCF_FLAG_REUSE_COND: the deepest level's conditional features and prior-head output depend on lr
+    // only (FlowNet_SR_x4.py:113-115, FlowNet_SR_x8.py:129): they sit at fixed arena offsets (first allocations of the pass) and
+    // survive until another kind of pass, another shape or a parameter change touches the arena.
+    const bool keep_c = (flags & (HCF_FLAG_KEEP_COND | HCF_FLAG_REUSE_COND)) != 0;
+    const bool reuse_c = (flags & HCF_FLAG_REUSE_COND) != 0 && cond_cache_ok(B, h, w);
+    Buf hkeep;
+    hkeep.p = nullptr;
     std::vector<Buf> cfb(L);
     Buf zprev;       // z buffer of the level processed before (deeper)
     zprev.p = nullptr;
@@ -903,7 +910,9 @@ struct hcf_engine {
       const CondFlow& cf = lv.cf;
       const int H = h << (L - 1 - level), W = w << (L - 1 - level);
       cfb[level] = alloc(B, H, W, cond_ch());
+      if (level == L - 1 && keep_c) hkeep = alloc(B, H, W, cf.Ca * 2);
       Buf z = alloc(B, H, W, lv.C);
+      const bool cached = reuse_c && level == L - 1;
       if (level == L - 1) {
         HCF_LAUNCH(launch_nchw_to_nhwc(lr, z.v(0, 3), B, 3, H, W, st));
       } else {
@@ -921,19 +930,22 @@ struct hcf_engine {
       std::vector<View> u;
       u.push_back(z.v(0, lv.ns));
       for (int l2 = level + 1; l2 < L; ++l2) u.push_back(cfb[l2].v(0, cond_ch(), l2 - level));
-      run_cond_features(cf, u, H, W, cfb[level], sc);
+      if (!cached) run_cond_features(cf, u, H, W, cfb[level], sc);
       const View cfv = cfb[level].v(0, cond_ch());
       // prior: a = mean + exp(logs) * eps   (ConditionalFlow.py:61-64 / 88-91)
-      run_conv(cf.head, {cfv}, H, W, sc.hout.v(0, cf.Ca * 2));
+      if (!cached) {
+        run_conv(cf.head, {cfv}, H, W, sc.hout.v(0, cf.Ca * 2));
+        if (level == L - 1 && keep_c) HCF_LAUNCH(launch_copy_view(sc.hout.v(0, cf.Ca * 2), hkeep.all(), B, H, W, st));
+      }
       {
         GaussArgs g;
         memset(&g, 0, sizeof(g));
         g.B = B; g.H = H; g.W = W; g.C = cf.Ca;
-        g.h = sc.hout.v(0, cf.Ca * 2);
+        g.h = (cached || (level == L - 1 && keep_c)) ? hkeep.all() : sc.hout.v(0, cf.Ca * 2);
         g.rescale = sr() ? 0 : 1;
         const int draw = L - 1 - level;
         g.eps = (eps && draw < n_eps) ? eps[draw] : nullptr;
-        g.tau = tau; g.seed = seed; g.offset = (uint64_t)draw;
+        g.tau = tau; g.seed = seed; g.offset = (uint64_t)draw; g.b0 = sample0;
         g.out = a.all();
         HCF_LAUNCH(launch_gauss_sample(g, st));
       }
@@ -947,6 +959,17 @@ struct hcf_engine {
         HCF_LAUNCH(launch_unsqueeze_nchw(z.all(), out, B, lv.C, H, W, cfg.squeeze == HCF_SQUEEZE_HAAR ? 1 : 0,
                                          (flags & HCF_FLAG_NO_CLAMP) ? 0 : 1, st));
     }
+    if (!dry() && rc == HCF_OK) {
+      if (keep_c) { cc_valid = true; cc_B = B; cc_h = h; cc_w = w; cc_f16 = use_f16; cc_base = arena.base; }
+      else cc_valid = false;
+    }
+  }
+  // state of the kept conditional features (see pass_inverse)
+  bool cc_valid = false, cc_f16 = false;
+  int cc_B = 0, cc_h = 0, cc_w = 0;
+  char* cc_base = nullptr;
+  bool cond_cache_ok(int B, int h, int w) const {
+    return cc_valid && cc_B == B && cc_h == h && cc_w == w && cc_f16 == use_f16 && cc_base == arena.base && arena.base != nullptr;
   }
 
   // ---------------------------------------------------------------- forward pass
@@ -1052,43 +1075,75 @@ struct hcf_engine {
 
 #include "hcf_engine_train.inc"
 
+  // Sizing: a dry walk of the pass measures the arena it needs; the result is cached per (pass kind, shape, flags, precision),
+  // so a steady-state call walks the graph ONCE and only enqueues (no allocation, no host-device synchronisation).
+  std::map<std::vector<long long>, size_t> plan_peak;
+  // f16x3 range flag: sticky on the device, mirrored into pinned host memory by an async copy at the end of every f16x3 pass;
+  // hcf_check_range() is the one call that waits for it.
+  int* ovf_host = nullptr;
+  hipEvent_t ovf_ev = nullptr;
+  bool ovf_pending = false;
+
   template <class F>
-  int run_pass(F&& body, hipStream_t stream, uint32_t flags = 0) {
+  int run_pass(F&& body, hipStream_t stream, uint32_t flags, std::vector<long long> key) {
     pass_flags = flags;
     if (!finalized) return fail(HCF_ERR_STATE, "hcf_finalize() has not been called");
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
     st = stream;
     use_f16 = (precision == PREC_F16X3) && !an_active;   // also during the sizing run: fusion decisions must not differ
-    arena.dry = true;
-    arena.peak = 0;
-    body();
-    arena.dry = false;
-    if (rc != HCF_OK) return rc;
-    if (ensure_arena(arena.peak) != HCF_OK) return rc;
-    use_f16 = (precision == PREC_F16X3) && !an_active;   // statistics passes run on the exact kernels
-    if (use_f16) {
-      if (!ovf_flag && hipMalloc((void**)&ovf_flag, 256) != hipSuccess)
-        return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
+    key.push_back((long long)flags);
+    key.push_back(use_f16 ? 1 : 0);
+    size_t need = 0;
+    auto it = an_active ? plan_peak.end() : plan_peak.find(key);
+    if (it != plan_peak.end()) {
+      need = it->second;
+    } else {
+      arena.dry = true;
+      arena.peak = 0;
+      body();
+      arena.dry = false;
+      if (rc != HCF_OK) return rc;
+      need = arena.peak;
+      if (!an_active) plan_peak[key] = need;
+    }
+    if (ensure_arena(need) != HCF_OK) return rc;
+    if (use_f16 && !ovf_flag) {
+      if (hipMalloc((void**)&ovf_flag, 256) != hipSuccess) return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
       if (hipMemsetAsync(ovf_flag, 0, 256, st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
     }
     body();
     if (use_f16 && rc == HCF_OK && !(pass_flags & HCF_FLAG_NO_RANGE_CHECK)) {
-      // an activation beyond the f16 range (|x| >= 65504) cannot be split: redo the pass exactly
-      int h = 0;
-      if (hipMemcpyAsync(&h, ovf_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess)
-        return fail(HCF_ERR_HIP, "reading the overflow flag failed");
-      if (h) {
-        n_fallbacks++;
-        use_f16 = false;
-        body();
-      }
+      // an activation beyond the f16 range (|x| >= 65504) cannot be split; the flag stays raised until hcf_check_range() reads it
+      if (!ovf_host && hipHostMalloc((void**)&ovf_host, 64, hipHostMallocDefault) != hipSuccess)
+        return fail(HCF_ERR_NOMEM, "hipHostMalloc failed for the range-flag mirror");
+      if (!ovf_ev && hipEventCreateWithFlags(&ovf_ev, hipEventDisableTiming) != hipSuccess)
+        return fail(HCF_ERR_HIP, "hipEventCreate failed");
+      if (hipMemcpyAsync(ovf_host, ovf_flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipEventRecord(ovf_ev, st) != hipSuccess)
+        return fail(HCF_ERR_HIP, "enqueueing the range-flag read-back failed");
+      ovf_pending = true;
     }
     use_f16 = false;
     an_active = false;
     an_pending.clear();
     return rc;
+  }
+  // 1: some f16x3 pass since the last check saw an input beyond the f16 range (its outputs are invalid: re-run it with
+  // HCF_PRECISION_EXACT); 0: none. Waits for the passes enqueued so far.
+  int check_range(int* overflowed) {
+    if (overflowed) *overflowed = 0;
+    if (!ovf_pending) return HCF_OK;
+    if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
+    if (hipEventSynchronize(ovf_ev) != hipSuccess) return fail(HCF_ERR_HIP, "hipEventSynchronize failed");
+    ovf_pending = false;
+    if (*ovf_host) {
+      if (overflowed) *overflowed = 1;
+      n_fallbacks++;
+      *ovf_host = 0;
+      if (hipMemsetAsync(ovf_flag, 0, sizeof(int), st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+    }
+    return HCF_OK;
   }
   uint32_t pass_flags = 0;
 };
@@ -1132,10 +1187,13 @@ void hcf_destroy(hcf_engine* e) {
   e->free_weights();
   if (e->arena.base) hipFree(e->arena.base);
   if (e->ovf_flag) hipFree(e->ovf_flag);
+  if (e->ovf_host) hipHostFree(e->ovf_host);
+  if (e->ovf_ev) hipEventDestroy(e->ovf_ev);
   if (e->stats_dev) hipFree(e->stats_dev);
   if (e->garena.base) hipFree(e->garena.base);
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
+  if (e->sum_jobs_dev) hipFree(e->sum_jobs_dev);
   if (e->rt.blob) hipFree(e->rt.blob);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
@@ -1185,6 +1243,7 @@ int hcf_finalize(hcf_engine* e, int device) {
   hipDeviceSynchronize();      // packed weights of a previous finalize may still be in use
   e->free_weights();
   e->train_ready = false;
+  e->cc_valid = false;
   e->invalidate_tapes();
   e->host_stale = false;
   e->device = device;
@@ -1197,11 +1256,24 @@ int hcf_finalize(hcf_engine* e, int device) {
   return HCF_OK;
 }
 
+int hcf_inverse_ex(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                   int64_t first_sample, float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream) {
+  if (!e || !lr || !out_hr || B < 1 || h < 1 || w < 1 || first_sample < 0) return HCF_ERR_ARG;
+  return e->run_pass([&]() { e->pass_inverse(lr, eps, n_eps, tau, seed, first_sample, out_hr, B, h, w, flags); },
+                     (hipStream_t)stream, flags, {1, B, h, w});
+}
+
 int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
                 float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream) {
-  if (!e || !lr || !out_hr || B < 1 || h < 1 || w < 1) return HCF_ERR_ARG;
-  return e->run_pass([&]() { e->pass_inverse(lr, eps, n_eps, tau, seed, out_hr, B, h, w, flags); }, (hipStream_t)stream,
-                     flags);
+  return hcf_inverse_ex(e, lr, eps, n_eps, tau, seed, 0, out_hr, B, h, w, flags, stream);
+}
+
+int hcf_check_range(hcf_engine* e, int32_t* overflowed) {
+  if (!e) return HCF_ERR_ARG;
+  int o = 0;
+  const int r = e->check_range(&o);
+  if (overflowed) *overflowed = o;
+  return r;
 }
 
 int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr, float* out_nll,
@@ -1210,8 +1282,8 @@ int hcf_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float*
   if (e->cfg.kind != HCF_KIND_SR) return e->fail(HCF_ERR_STATE, "hcf_forward_sr on a rescaling engine"), HCF_ERR_STATE;
   const int m = 1 << e->cfg.L;
   if (H % m || W % m) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by the scale (squeeze2d assert, Basic.py:136)"), HCF_ERR_SHAPE;
-  return e->run_pass([&]() { e->pass_forward(hr, lr, noise, out_lr, out_nll, out_logdet, out_z, nullptr, nullptr, B, H, W, 0); },
-                     (hipStream_t)stream);
+  return e->run_pass([&]() { e->cc_valid = false; e->pass_forward(hr, lr, noise, out_lr, out_nll, out_logdet, out_z, nullptr, nullptr, B, H, W, 0); },
+                     (hipStream_t)stream, 0, {2, B, H, W, lr ? 1 : 0, noise ? 1 : 0, out_z ? 1 : 0});
 }
 
 int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* out_z1, float* out_z2, int32_t B, int32_t H,
@@ -1220,8 +1292,8 @@ int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* ou
   if (e->cfg.kind != HCF_KIND_RESCALING) return e->fail(HCF_ERR_STATE, "hcf_forward_rescale on an SR engine"), HCF_ERR_STATE;
   const int m = 1 << e->cfg.L;
   if (H % m || W % m) return e->fail(HCF_ERR_SHAPE, "H, W must be divisible by 4"), HCF_ERR_SHAPE;
-  return e->run_pass([&]() { e->pass_forward(hr, nullptr, nullptr, out_lr, nullptr, nullptr, nullptr, out_z1, out_z2, B, H, W, flags); },
-                     (hipStream_t)stream);
+  return e->run_pass([&]() { e->cc_valid = false; e->pass_forward(hr, nullptr, nullptr, out_lr, nullptr, nullptr, nullptr, out_z1, out_z2, B, H, W, flags); },
+                     (hipStream_t)stream, flags, {3, B, H, W});
 }
 
 int hcf_set_precision(hcf_engine* e, int32_t mode) {

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gauss_sample_kernel(const GaussArgs a) {
     const size_t e = ((size_t)b * a.C + c) * hw + i;           // NCHW element index
     float eps;
     if (a.eps) eps = a.eps[e];
-    else eps = (a.tau == 0.f) ? 0.f : a.tau * philox_normal(a.seed, a.offset, e);
+    else eps = (a.tau == 0.f) ? 0.f : a.tau * philox_normal(a.seed, a.offset, e + (size_t)a.b0 * a.C * hw);
     op[c] = mean + expf(logs) * eps;
   }
 }

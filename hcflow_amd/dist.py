@@ -22,12 +22,14 @@ def shard_bounds(B: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, group=None,
-                  extras: Optional[Sequence[Optional[torch.Tensor]]] = None) -> torch.Tensor:
+def sharded_apply(fn: Callable[..., torch.Tensor], x: torch.Tensor, group=None,
+                  extras: Optional[Sequence[Optional[torch.Tensor]]] = None, with_offset: bool = False) -> torch.Tensor:
     """Run ``fn`` on this rank's batch shard of ``x`` (and of each tensor in ``extras``) and
-    all-gather the outputs along dim 0. Every rank passes the same full ``x`` and gets the same full result."""
+    all-gather the outputs along dim 0. Every rank passes the same full ``x`` and gets the same full result.
+    ``with_offset``: ``fn`` also receives ``offset=`` the index of the shard's first sample in the full batch."""
     if not (dist.is_available() and dist.is_initialized()):
-        return fn(x) if extras is None else fn(x, *extras)
+        kw = {"offset": 0} if with_offset else {}
+        return fn(x, **kw) if extras is None else fn(x, *extras, **kw)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = x.shape[0]
     lo, hi = shard_bounds(B, world, rank)
@@ -36,12 +38,12 @@ def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, g
         args = [x[lo:hi]]
         if extras is not None:
             args += [None if e is None else e[lo:hi] for e in extras]
-        y = fn(*args)
+        y = fn(*args, **({"offset": lo} if with_offset else {}))
     else:                                     # more ranks than samples: run one sample to learn the shape
         args = [x[:1]]
         if extras is not None:
             args += [None if e is None else e[:1] for e in extras]
-        y = fn(*args)[:0]
+        y = fn(*args, **({"offset": 0} if with_offset else {}))[:0]
     pad = torch.zeros((n_max,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
     pad[: y.shape[0]] = y
     out = torch.empty((world * n_max,) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
@@ -55,13 +57,31 @@ def sharded_apply(fn: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, g
     return torch.cat(pieces, 0)
 
 
-def sharded_inverse(net, lr: torch.Tensor, eps_std: float, eps: Optional[Sequence[torch.Tensor]] = None, group=None):
+def common_seed(device, group=None, seed: Optional[int] = None) -> int:
+    """One Philox seed for the whole sharded batch: rank 0's draw (it follows torch.manual_seed there), broadcast."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if not (dist.is_available() and dist.is_initialized()):
+        return seed
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([seed], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
+
+
+def sharded_inverse(net, lr: torch.Tensor, eps_std: float, eps: Optional[Sequence[torch.Tensor]] = None, group=None,
+                    seed: Optional[int] = None):
     """netG(lr=..., eps_std=..., reverse=True) over a batch sharded across the ranks of ``group``.
 
     ``eps`` (optional, parity runs): full-batch N(0, tau) tensors in sampling order; each rank uses its slice.
+    Without ``eps`` the draws happen on the device: every rank uses the SAME seed and the offset of its shard in the batch, so
+    sample k of the gathered batch gets the eps sample k would get on one GPU (hcf_inverse_ex) -- the reference seeds all ranks
+    identically (train_HCFlow.py:43-46), which with shard-local indexing would repeat the same eps in every shard.
     """
     if eps is None:
-        return sharded_apply(lambda s: net(lr=s, z=None, u=None, eps_std=eps_std, reverse=True), lr, group)
+        sd = common_seed(lr.device, group, seed)
+        return sharded_apply(lambda s, offset: net(lr=s, z=None, u=None, eps_std=eps_std, reverse=True, seed=sd,
+                                                   sample_offset=offset), lr, group, with_offset=True)
     return sharded_apply(lambda s, *e: net(lr=s, z=None, u=None, eps_std=eps_std, reverse=True, eps=list(e)),
                          lr, group, extras=list(eps))
 

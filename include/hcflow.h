@@ -11,9 +11,10 @@
  * Conventions: plain pointers and sizes, no torch types. Return 0 on success, a negative HCF_ERR_*
  * code otherwise (never throws); hcf_last_error() gives a message. Image tensors are dense NCHW
  * fp32 DEVICE pointers owned by the caller; parameters are passed as HOST pointers and packed /
- * uploaded by hcf_finalize(). All work is enqueued on the caller's HIP stream; no hidden device
- * synchronisation happens inside hcf_inverse / hcf_forward_* once the workspace has reached its
- * steady-state size (first call per shape may allocate).
+ * uploaded by hcf_finalize(). All work is enqueued on the caller's HIP stream; hcf_inverse / hcf_forward_sr /
+ * hcf_forward_rescale never synchronise with the device once the workspace has reached its steady-state size (the first call
+ * per shape sizes and may allocate it): a steady-state call walks the layer graph once and returns, so it can be captured into
+ * a HIP graph. The f16x3 range flag is read back asynchronously; hcf_check_range() is the call that waits for it.
  */
 #ifndef HCFLOW_H_
 #define HCFLOW_H_
@@ -48,7 +49,12 @@ extern "C" {
 
 /* flags for hcf_inverse / hcf_forward_* */
 #define HCF_FLAG_NO_CLAMP 1u        /* return the flow output before torch.clamp(.,0,1) (parity tests) */
-#define HCF_FLAG_NO_RANGE_CHECK 2u  /* f16x3 mode: skip the end-of-pass range check (no stream sync, no exact re-run) */
+#define HCF_FLAG_NO_RANGE_CHECK 2u  /* f16x3 mode: do not even enqueue the read-back of the range flag (hcf_check_range) */
+#define HCF_FLAG_KEEP_COND 4u       /* hcf_inverse: compute the deepest level's conditional features + prior head and keep them */
+#define HCF_FLAG_REUSE_COND 8u      /* hcf_inverse: the caller asserts that lr (contents, B, h, w) is the one of the previous
+                                     * KEEP / REUSE call: the kept features are used if still valid (else recomputed and kept).
+                                     * They depend on lr only (FlowNet_SR_x4.py:113-115, FlowNet_SR_x8.py:129), so a tau sweep or
+                                     * repeated sampling of one LR batch skips that level's RRDB trunks; results are bit-identical. */
 
 /* numerics of the convolutions (hcf_set_precision) */
 #define HCF_PRECISION_EXACT 0       /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32) */
@@ -107,6 +113,12 @@ int hcf_finalize(hcf_engine* e, int device);
  *   out_hr  [B,3,h*scale,w*scale] device */
 int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
                 float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
+/* The same for a SHARD of a larger batch (batch-sharded multi-GPU sampling): sample b of this call is sample
+ * first_sample + b of the batch, and the device Philox draws are those of that global sample -- N shards with the same seed
+ * reproduce the one-GPU batch bit for bit (the reference seeds every rank identically, train_HCFlow.py:43-46, which would give
+ * every shard the same eps). hcf_inverse = first_sample 0. */
+int hcf_inverse_ex(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
+                   int64_t first_sample, float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
 
 /* netG(hr=hr, lr=lr, reverse=False) for HCFlowNet_SR: normal_flow_diracLR (HCFlowNet_SR_arch.py:47-67).
  *   hr [B,3,H,W], lr [B,3,H/scale,W/scale] (NULL -> no Dirac term), noise [B,3,H,W] U[0,1) or NULL
@@ -124,11 +136,15 @@ int hcf_forward_rescale(hcf_engine* e, const float* hr, float* out_lr, float* ou
 /* Convolution numerics. HCF_PRECISION_EXACT (default): fp32 MFMA, an exact fp32 fma chain.
  * HCF_PRECISION_F16X3: every fp32 product is formed from f16 hi/lo parts (a_hi b_hi + a_hi b_lo +
  * a_lo b_hi, error ~2^-22) on the 16x faster f16 matrix cores with fp32 accumulation; deviation
- * from fp64 on the full nets equals plain fp32's. Inputs beyond the f16 range raise
- * a device flag: the pass is then transparently re-run exactly (one stream sync per pass; see
- * HCF_FLAG_NO_RANGE_CHECK). hcf_fallback_count = number of passes that were re-run. */
+ * from fp64 on the full nets equals plain fp32's. An input beyond the f16 range (|x| >= 65504) cannot be
+ * split: it raises a sticky device flag whose value every f16x3 inference pass copies to pinned host memory asynchronously.
+ * hcf_check_range waits for the passes enqueued so far and reports (and clears) it: *overflowed = 1 means the outputs of the
+ * f16x3 passes since the last check are invalid and must be recomputed with HCF_PRECISION_EXACT (hcflow_amd/arch.py does that
+ * by default after every pass; `set_range_check("lazy")` defers it). hcf_fallback_count = number of raised checks. The taped
+ * training passes (hcf_train_*) check and re-run by themselves (they synchronise anyway). */
 int hcf_set_precision(hcf_engine* e, int32_t mode);
 int hcf_get_precision(const hcf_engine* e);
+int hcf_check_range(hcf_engine* e, int32_t* overflowed);
 int64_t hcf_fallback_count(const hcf_engine* e);
 
 /* bytes of device workspace currently held (activations arena) and of packed weights */

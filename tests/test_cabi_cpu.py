@@ -78,3 +78,43 @@ def test_from_opt_roundtrip_and_eps_shapes():
         assert param_spec(cfg) == param_spec(cfg2)
     assert eps_shapes(preset("SR_DF2K_4X"), 16, 160, 160) == [(16, 21, 160, 160), (16, 6, 320, 320)]
     assert eps_shapes(preset("SR_CelebA_8X"), 2, 20, 20) == [(2, 45, 20, 20), (2, 12, 40, 40), (2, 6, 80, 80)]
+
+
+def test_default_precision_and_policies(monkeypatch):
+    """The drop-in default is the mode bench.py reports as its headline: f16x3 with the synchronous range check (an
+    overflowed pass is re-run exactly); HCFLOW_PRECISION / HCFLOW_RANGE_CHECK override it for unmodified driver scripts."""
+    from hcflow_amd.arch import HCFlowNet_SR
+    cfg = preset("SR_4X_tiny")
+    monkeypatch.delenv("HCFLOW_PRECISION", raising=False)
+    monkeypatch.delenv("HCFLOW_RANGE_CHECK", raising=False)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    assert net._precision[0] == "f16x3" and net._range_check[0] == "sync"
+    monkeypatch.setenv("HCFLOW_PRECISION", "exact")
+    assert HCFlowNet_SR(opt=cfg.to_opt(), step=0)._precision[0] == "exact"
+    net.set_precision("exact").set_range_check("lazy")
+    assert net._precision[0] == "exact" and net._range_check[0] == "lazy"
+    with pytest.raises(AssertionError):
+        net.set_range_check("sometimes")
+
+
+def test_parameters_resolve_through_attributes_on_dataparallel_replicas():
+    """nn.DataParallel replicas (torch >= 1.5) have no registered parameters: the module must find its tensors through the
+    attribute tree (hcflow_amd/arch.py: _tensors), in state_dict order, and see requires_grad on them."""
+    from hcflow_amd.arch import HCFlowNet_SR
+    cfg = preset("SR_4X_tiny")
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    keys = [k for k, _, _ in param_spec(cfg)]
+    got = net._tensors()
+    assert [k for k, _ in got] == keys
+    sd = dict(net.named_parameters())
+    assert all(t is sd[k] for k, t in got)
+    replica = net._replicate_for_data_parallel()          # what torch.nn.parallel.replicate starts from
+    for m in replica.modules():                           # ... and then strips, re-attaching plain tensors
+        for name, p_ in list(m._parameters.items()):
+            if p_ is not None:
+                m._parameters[name] = None
+                object.__setattr__(m, name, p_.detach().clone().requires_grad_(p_.requires_grad) * 1.0)
+    assert len(list(replica.parameters())) == 0
+    rt = replica._tensors()
+    assert [k for k, _ in rt] == keys and all(torch.is_tensor(t) for _, t in rt)
+    assert replica._wants_grad() and rt[0][1].device.type == "cpu"

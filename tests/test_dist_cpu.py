@@ -55,6 +55,23 @@ def _worker(rank, world, port, B, q):
         with torch.no_grad():
             ref = O.sr_inverse(lr, p, cfg, 0.8, eps)
         ok = out.shape == ref.shape and float((out - ref).abs().max()) <= 1e-5
+        # device-sampling path: every shard is called with the common seed and ITS offset into the batch
+        seen = []
+
+        class Net2:
+            def __call__(self, lr=None, z=None, u=None, eps_std=None, reverse=False, seed=None, sample_offset=0):
+                seen.append((int(seed), int(sample_offset), int(lr.shape[0])))
+                return lr * 2
+
+        torch.manual_seed(100 + rank)                 # ranks disagree on their local RNG: rank 0's draw must win
+        out2 = sharded_inverse(Net2(), lr, 0.8)
+        ok = ok and torch.equal(out2, lr * 2)
+        from hcflow_amd.dist import shard_bounds as sb
+        lo, hi = sb(B, dist.get_world_size(), rank)
+        seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(dist.get_world_size())]
+        dist.all_gather(seeds, torch.tensor([seen[0][0]], dtype=torch.int64))
+        ok = ok and len({int(t) for t in seeds}) == 1
+        ok = ok and (seen[0][1:] == (lo, hi - lo) if hi > lo else seen[0][1:] == (0, 1))
         # generic path, shards see only their slice
         y = sharded_apply(lambda s: s * 2 + 1, torch.arange(B * 3, dtype=torch.float32).view(B, 3))
         ok = ok and torch.equal(y, torch.arange(B * 3, dtype=torch.float32).view(B, 3) * 2 + 1)
@@ -69,6 +86,44 @@ def test_sharded_inverse_gloo_world2(B):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p_ in procs:
+        p_.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def _an_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hcflow_amd.arch import HCFlowNet_SR, ActNorm2d
+        from hcflow_amd.config import preset
+        cfg = preset("SR_4X_tiny")
+        torch.manual_seed(0)
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        an = [(k, m) for k, m in net.named_modules() if isinstance(m, ActNorm2d)]
+        with torch.no_grad():
+            for i, (_, m) in enumerate(an):                       # every rank "fitted" different values
+                m.bias.fill_(1.0 + rank + 0.01 * i)
+                m.logs.fill_(-0.5 * (rank + 1) + 0.01 * i)
+        net._broadcast_actnorms(an)
+        ok = all(float(m.bias.flatten()[0]) == pytest.approx(1.0 + 0.01 * i) and
+                 float(m.logs.flatten()[0]) == pytest.approx(-0.5 + 0.01 * i) for i, (_, m) in enumerate(an))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_actnorm_init_is_broadcast_from_rank0_world2():
+    """ActNorms.py:28-44 fits every rank's ActNorms to its own shard; the module broadcasts rank 0's fit so the DDP replicas
+    start from one parameter set."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_an_worker, args=(r, 2, port, q)) for r in range(2)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=180) for _ in range(2)]

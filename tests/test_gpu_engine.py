@@ -1,0 +1,166 @@
+"""-m gpu: engine-level behaviour added in round 2 -- global-sample Philox offsets for batch shards, kept conditional
+features across tau / samples (BASELINE.json config 3), the asynchronous f16x3 range check with its exact re-run, a steady-state
+pass that only enqueues (HIP-graph capture), and nn.DataParallel-style replicas."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(name, seed, precision, cls=None):
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    from hcflow_amd.config import preset
+    from tests.util import cached_params
+    cfg = preset(name)
+    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(cached_params(name, seed), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    return cfg, net.to("cuda:0").eval().set_precision(precision)
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+@pytest.mark.parametrize("name", ["SR_4X_tiny", "SR_8X_tiny", "Rescaling_4X_tiny"])
+def test_shards_with_sample_offsets_reproduce_the_full_batch(name, precision):
+    """hcf_inverse_ex: shard r samples the eps of global samples [lo, hi): two half batches (and a 3 + 2 split) with the common
+    seed equal the one-GPU batch bit for bit; without the offset the second shard would repeat the first shard's draws."""
+    cfg, net = _net(name, 11, precision)
+    g = torch.Generator().manual_seed(3)
+    lr = torch.rand(5, 3, 12, 16, generator=g).cuda()
+    with torch.no_grad():
+        full = net(lr=lr, eps_std=0.8, reverse=True, seed=1234)
+        parts = [net(lr=lr[lo:hi].contiguous(), eps_std=0.8, reverse=True, seed=1234, sample_offset=lo)
+                 for lo, hi in ((0, 3), (3, 5))]
+        assert torch.equal(torch.cat(parts, 0), full)
+        naive = net(lr=lr[3:5].contiguous(), eps_std=0.8, reverse=True, seed=1234)
+        assert not torch.equal(naive, full[3:5])
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+@pytest.mark.parametrize("name", ["SR_8X_tiny", "SR_4X_tiny"])
+def test_kept_conditional_features_are_bit_identical_over_a_tau_sweep(name, precision):
+    """Config 3 (diverse sampling): the deepest level's conditional features + prior head depend on lr only
+    (FlowNet_SR_x8.py:129): cache_cond=True keeps them across tau / samples; outputs equal the uncached ones bit for bit, and
+    the cache is dropped when lr or a parameter changes."""
+    cfg, net = _net(name, 12, precision)
+    g = torch.Generator().manual_seed(4)
+    lr = torch.rand(3, 3, 8, 12, generator=g).cuda()
+    taus = [0.0, 0.3, 0.8, 0.8]
+    with torch.no_grad():
+        want = [net(lr=lr, eps_std=t, reverse=True, seed=50 + i) for i, t in enumerate(taus)]
+        got = [net(lr=lr, eps_std=t, reverse=True, seed=50 + i, cache_cond=True) for i, t in enumerate(taus)]
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        # an in-place change of lr must not be served from the cache
+        lr.mul_(0.5)
+        a = net(lr=lr, eps_std=0.5, reverse=True, seed=9, cache_cond=True)
+        b = net(lr=lr, eps_std=0.5, reverse=True, seed=9)
+        assert torch.equal(a, b)
+        # ... nor a parameter update
+        for p in net.parameters():
+            if p.dim() == 4 and p.shape[1] > 1 and float(p.abs().max()) > 0:
+                p.mul_(1.01)
+                break
+        a = net(lr=lr, eps_std=0.5, reverse=True, seed=9, cache_cond=True)
+        b = net(lr=lr, eps_std=0.5, reverse=True, seed=9)
+        assert torch.equal(a, b)
+        # a different pass in between (forward) invalidates the kept buffers inside the engine
+        a1 = net(lr=lr, eps_std=0.5, reverse=True, seed=9, cache_cond=True)
+        hr = torch.rand(3, 3, 8 * cfg.scale, 12 * cfg.scale, generator=g).cuda()
+        net(hr=hr, lr=lr, reverse=False)
+        a2 = net(lr=lr, eps_std=0.5, reverse=True, seed=9, cache_cond=True)
+        assert torch.equal(a1, a2) and torch.equal(a2, b)
+
+
+def test_range_overflow_is_rerun_exactly_in_sync_mode_and_reported_in_lazy_mode():
+    """|activation| >= 65504 cannot be split into f16 hi / lo parts. sync (default): the module asks the engine after the pass
+    and redoes it on the exact kernels; lazy: nothing waits, check_range() reports it."""
+    cfg, net = _net("SR_4X_tiny", 11, "f16x3")
+    g = torch.Generator().manual_seed(5)
+    lr = (torch.rand(2, 3, 12, 12, generator=g) * 2e5).cuda()
+    ok_lr = torch.rand(2, 3, 12, 12, generator=g).cuda()
+    with torch.no_grad():
+        n0 = net.engine().fallback_count()
+        out = net(lr=lr, eps_std=0.5, reverse=True, seed=3)
+        assert net.engine().fallback_count() == n0 + 1
+        net.set_precision("exact")
+        ref = net(lr=lr, eps_std=0.5, reverse=True, seed=3)
+        net.set_precision("f16x3")
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+        # an in-range pass afterwards is not affected (the flag was cleared)
+        a = net(lr=ok_lr, eps_std=0.5, reverse=True, seed=3)
+        assert net.engine().fallback_count() == n0 + 1 and bool(torch.isfinite(a).all())
+        net.set_range_check("lazy")
+        assert net.check_range() is False
+        net(lr=ok_lr, eps_std=0.5, reverse=True, seed=3)
+        assert net.check_range() is False
+        net(lr=lr, eps_std=0.5, reverse=True, seed=3)
+        net(lr=ok_lr, eps_std=0.5, reverse=True, seed=3)          # the flag is sticky until somebody asks
+        assert net.check_range() is True
+        assert net.check_range() is False
+        b = net(lr=ok_lr, eps_std=0.5, reverse=True, seed=3)
+        assert torch.equal(a, b)
+        net.set_range_check("sync")
+
+
+@pytest.mark.parametrize("precision", ["exact", "f16x3"])
+def test_steady_state_inverse_only_enqueues_and_can_be_graph_captured(precision):
+    """With the plan cached and the range flag read back asynchronously a steady-state call contains no allocation and no
+    host-device synchronisation: the whole pass can be captured into a HIP graph and replayed (bit-identical to eager)."""
+    cfg, net = _net("SR_4X_tiny", 11, precision)
+    net.set_range_check("lazy")
+    g = torch.Generator().manual_seed(6)
+    lr = torch.rand(2, 3, 16, 16, generator=g).cuda()
+    with torch.no_grad():
+        eager = net(lr=lr, eps_std=0.8, reverse=True, seed=77)        # also sizes the workspace
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            net(lr=lr, eps_std=0.8, reverse=True, seed=77)            # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            out = net(lr=lr, eps_std=0.8, reverse=True, seed=77)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        lr.copy_(torch.rand(2, 3, 16, 16, generator=g))               # new LR contents, same graph
+        graph.replay()
+        torch.cuda.synchronize()
+        again = net(lr=lr, eps_std=0.8, reverse=True, seed=77)
+        assert torch.equal(out, again)
+    assert net.check_range() is False
+
+
+def test_dataparallel_replica_forward_and_backward():
+    """What nn.DataParallel does on every forward (HCFlow_SR_model.py:33-36, non-distributed): replicate -> replicas whose
+    parameters are plain tensor attributes -> forward -> backward through Broadcast into the wrapped module's .grad."""
+    from torch.nn.parallel import replicate
+    cfg, net = _net("SR_4X_tiny", 11, "exact")
+    net.train()
+    g = torch.Generator().manual_seed(8)
+    hr = torch.rand(2, 3, 32, 48, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+    nll.backward()
+    want = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    replica = replicate(net, [torch.device("cuda", 0)])[0]
+    assert len(list(replica.parameters())) == 0
+    _, nll2 = replica(hr=hr, lr=lr, reverse=False, noise=noise)
+    nll2.backward()
+    assert float(nll2.detach()) == float(nll.detach())
+    for p, w in zip(net.parameters(), want):
+        assert p.grad is not None and torch.equal(p.grad, w)
+    with torch.no_grad():                                             # inference on a replica as well
+        a = replica(lr=lr, eps_std=0.7, reverse=True, seed=5)
+        b = net(lr=lr, eps_std=0.7, reverse=True, seed=5)
+    assert torch.equal(a, b)
+    wrapped = torch.nn.DataParallel(net, device_ids=[0])
+    _, nll3 = wrapped(hr=hr, lr=lr, reverse=False, noise=noise)
+    assert float(nll3.detach()) == float(nll.detach())
