@@ -26,13 +26,11 @@ struct View {
   int c0;     // first channel of the window
   int n;      // channels in the window
   int up;     // log2 nearest-upsample factor when read as a conv source (0 = none)
-  int fmt;    // 0: fp32; 1: split16 (hcf_conv_f16x3_dma.hip: each aligned 16-channel group = [16 hi | 16 lo] f16, same bytes)
 };
 
 static inline View mkview(float* p, int cs, int c0, int n, int up = 0) {
-  View v; v.p = p; v.cs = cs; v.c0 = c0; v.n = n; v.up = up; v.fmt = 0; return v;
+  View v; v.p = p; v.cs = cs; v.c0 = c0; v.n = n; v.up = up; return v;
 }
-static inline View as_split16(View v) { v.fmt = 1; return v; }
 
 constexpr int kMaxSrc = 3;
 
@@ -61,8 +59,7 @@ struct ConvArgs {
   View tz; View tzo; const float* tmat; const float* tbias; const float* tmul; int tC, tns, tmode;
   const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
   const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
-  unsigned long long* dbg; // optional: block 0 writes {shader cycles, 100 MHz ticks} of its lifetime
-  int dbg_bits;            // hcf_conv_f16x3_dma.hip timing ablations (tools/conv_bench.py --ablate (bits << 8) | 32), 0 = off
+  unsigned long long* dbg; // HCF_CONV_TIMERS builds only (tools/conv_bench.py): phase timers of a few mid-grid blocks
   int vec_epi;             // f16x3 kernel, set by the launcher: out / residual views allow 16-byte accesses -> LDS-transposed epilogue
 };
 
@@ -81,11 +78,6 @@ enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 // fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
-// split16-source variant staged by LDS-DMA (hcf_conv_f16x3_dma.hip); HCF_ERR_UNSUPPORTED when the launch does not qualify
-int launch_conv_f16x3_dma(const ConvArgs& a, hipStream_t st);
-int launch_to_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);
-int launch_from_split16(const View& src, const View& dst, int B, int H, int W, hipStream_t st);
-int launch_max_abs_diff(const float* a, const float* b, size_t n, unsigned* out_bits, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------
 // dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)

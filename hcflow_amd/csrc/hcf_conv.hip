@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+#ifdef HCF_CONV_TIMERS      // clock probe of tools/conv_bench.py: measurement builds only (make TIMERS=1)
   const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
   const int H = a.H, W = a.W;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -207,10 +209,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
+#ifdef HCF_CONV_TIMERS
   if (a.dbg && (blockIdx.x & 1023) == 512 && tid == 0) {   // a few mid-grid blocks: shader clock vs 100 MHz reference
     atomicAdd(a.dbg + 0, __builtin_readcyclecounter() - dbg_c0);
     atomicAdd(a.dbg + 1, __builtin_amdgcn_s_memrealtime() - dbg_r0);
   }
+#endif
 
   // ---- epilogue --------------------------------------------------------------------------------
   // Residual reads go out RB at a time before the first is consumed (see hcf_conv_f16x3.hip: one s_waitcnt per value
@@ -302,11 +306,10 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   bool vec = true;
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
-    if (a.src[i].fmt != 0) return HCF_ERR_ARG;      // split16 tensors belong to the f16x3 LDS-DMA kernel
   }
   ConvArgs b = a;
   auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
-  b.vec_epi = a.out.p && (a.out.n & 3) == 0 && a.out.fmt == 0 && v4(a.out) && v4(a.res1) && v4(a.res2);
+  b.vec_epi = a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2);
   if (vec)
     hipLaunchKernelGGL((conv_mfma_kernel<TAPS, NT, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else

@@ -126,8 +126,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, li = lane & 31;
+#ifdef HCF_CONV_TIMERS      // phase timers of tools/conv_bench.py: measurement builds only (make TIMERS=1), never in the product .so
   const unsigned long long dbg_c0 = a.dbg ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long dbg_r0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
   const int wm = (NTB == 2) ? (wave >> 1) : wave;   // which group of MT tile rows
   const int wn = (NTB == 2) ? (wave & 1) : 0;       // which 32-channel n tile
   const int H = a.H, W = a.W;
@@ -260,14 +262,21 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int abase = ((MT * wm) * HW + li) * REC + half * 16;
   const int bbase = half * BHALF + (wn * 32 + li) * 16;
 
+#ifdef HCF_CONV_TIMERS
   const bool dbg_on = a.dbg && (blockIdx.x & 1023) == 512 && tid == 0;     // a few mid-grid blocks
   const unsigned long long dbg_ra = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
   HCF_STAGE_LOAD(0);
+#ifdef HCF_CONV_TIMERS
   const unsigned long long dbg_rb = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
   HCF_STAGE_SPLIT();
+#ifdef HCF_CONV_TIMERS
   const unsigned long long dbg_rc = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
   HCF_STAGE_WRITE();
   __syncthreads();
+#ifdef HCF_CONV_TIMERS
   const unsigned long long dbg_r1 = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (dbg_on) {
     atomicAdd(a.dbg + 6, dbg_ra - dbg_r0);
@@ -275,6 +284,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     atomicAdd(a.dbg + 8, dbg_rc - dbg_rb);
     atomicAdd(a.dbg + 9, dbg_r1 - dbg_rc);
   }
+#endif
 
   f32x16 acc[MT];
 #pragma unroll
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
 #undef HCF_STAGE_SPLIT
 #undef HCF_STAGE_WRITE
 
+#ifdef HCF_CONV_TIMERS
   unsigned long long dbg_r2 = 0ull;
   if (dbg_on) {   // shader clock vs 100 MHz reference; {prologue, chunk loop, epilogue} in 100 MHz ticks at [2..4], blocks at [5]
     dbg_r2 = __builtin_amdgcn_s_memrealtime();
@@ -344,6 +355,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     atomicAdd(a.dbg + 5, 1ull);
   }
 #define HCF_DBG_EPI() { if (dbg_on) atomicAdd(a.dbg + 4, __builtin_amdgcn_s_memrealtime() - dbg_r2); }
+#else
+#define HCF_DBG_EPI()
+#endif
 
   // ---- epilogue (same algebra as the fp32 kernel) ---------------------------------------------
   const int cout = a.out.n;

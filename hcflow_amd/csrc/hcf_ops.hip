@@ -506,48 +506,6 @@ extern "C" int hcf_bench_conv(int32_t B, int32_t H, int32_t W, const int32_t* sr
       fprintf(stderr, "block phases (avg of %llu blocks): prologue %.2f us, chunk loop %.2f us, epilogue %.2f us\n", hd[5],
               hd[2] / 100.0 / hd[5], hd[3] / 100.0 / hd[5], hd[4] / 100.0 / hd[5]);
   }
-  if (rc == HCF_OK && f16 && k == 3 && (g_f16x3_ablation & 32)) {
-    // experiment: the same conv with split16 sources staged by LDS-DMA; a.out (regular kernel) is the reference
-    ConvArgs d = a;
-    for (int i = 0; i < n_src && rc == HCF_OK; ++i) {
-      const size_t n = (size_t)B * H * W * a.src[i].cs;
-      d.src[i] = as_split16(mkview(t.dev(n), a.src[i].cs, 0, a.src[i].n));
-      if (!t.ok) return HCF_ERR_NOMEM;
-      rc = launch_to_split16(a.src[i], d.src[i], B, H, W, st);
-    }
-    for (int i = n_src; i < kMaxSrc; ++i) d.src[i] = d.src[0];
-    const size_t nout = (size_t)B * H * W * a.out.cs;
-    d.out = mkview(t.dev(nout), a.out.cs, 0, cout);
-    unsigned* diff = (unsigned*)t.dev(1);
-    if (!t.ok) return HCF_ERR_NOMEM;
-    d.dbg = (unsigned long long*)t.dev(16);
-    if (!t.ok) return HCF_ERR_NOMEM;
-    d.dbg_bits = (g_f16x3_ablation >> 8) & 0xff;
-    hipMemsetAsync(diff, 0, 4, st);
-    hipMemsetAsync(d.out.p, 0, nout * 4, st);
-    hipMemsetAsync(a.out.p, 0, nout * 4, st);
-    if (rc == HCF_OK) rc = launch_conv_f16x3(a, 9, st);
-    if (rc == HCF_OK) rc = launch_conv_f16x3_dma(d, st);
-    if (rc == HCF_OK) rc = launch_max_abs_diff(a.out.p, d.out.p, nout, diff, st);
-    hipMemsetAsync(d.dbg, 0, 64, st);
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    hipEventRecord(e0, st);
-    for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = launch_conv_f16x3_dma(d, st);
-    hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess) rc = HCF_ERR_HIP;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    unsigned bits = 0;
-    hipMemcpy(&bits, diff, 4, hipMemcpyDeviceToHost);
-    g_last_clock_mhz = (double)__builtin_bit_cast(float, bits);     // reported in the clk column: max |dma - regular|
-    unsigned long long hd[5] = {0, 0, 0, 0, 0};
-    hipMemcpy(hd, d.dbg, 40, hipMemcpyDeviceToHost);
-    if (hd[4])
-      fprintf(stderr, "dma tile phases (avg of %llu tiles): chunk loops %.2f us, epilogue %.2f us, clock %.0f MHz\n",
-              hd[4], hd[1] / 100.0 / hd[4], hd[2] / 100.0 / hd[4], 100.0 * hd[3] / (double)(hd[1] + hd[2]));
-  }
   if (ms_per_launch) *ms_per_launch = ms / iters;
   if (flops_per_launch) *flops_per_launch = 2.0 * k * k * cin * (double)cout * B * H * W;
   return rc;

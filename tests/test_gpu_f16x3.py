@@ -177,34 +177,3 @@ def test_large_grid_forward_nll_f16x3_is_deterministic():
 
 def _as_list(z):
     return list(z) if isinstance(z, (list, tuple)) else [z]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("shape", [
-    # B, H, W, source channels, out channels: ragged tiles (H, W not multiples of 16 / 32), 1..3 sources, both n-tile counts
-    (2, 40, 72, [64, 32], 32),
-    (1, 50, 33, [64, 128], 64),
-    (3, 16, 32, [16], 16),
-    (1, 97, 130, [64, 64, 32], 48),
-])
-def test_lds_dma_experiment_is_bit_identical(shape):
-    """hcf_conv_f16x3_dma.hip (bench-only experiment: split16 sources staged by LDS-DMA, persistent blocks) must
-    reproduce the shipped f16x3 kernel bit for bit -- same split, same accumulation order."""
-    import ctypes as C
-    import torch
-    from hcflow_amd import _lib
-    lib = _lib.load()
-    B, H, W, srcs, cout = shape
-    assert lib.hcf_op_set_precision(_lib.Engine.PRECISIONS["f16x3"]) == 0
-    assert lib.hcf_debug_set_ablation(32) == 0
-    try:
-        torch.cuda.init()
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        arr = (C.c_int32 * len(srcs))(*srcs)
-        ms, fl = C.c_double(), C.c_double()
-        rc = lib.hcf_bench_conv(B, H, W, arr, len(srcs), cout, 3, 2, C.byref(ms), C.byref(fl), st)
-        assert rc == 0, rc
-        assert lib.hcf_debug_last_clock_mhz() == 0.0      # with --ablate 32 this slot carries max |dma - shipped|
-    finally:
-        lib.hcf_debug_set_ablation(0)
-        lib.hcf_op_set_precision(_lib.Engine.PRECISIONS["exact"])

@@ -203,8 +203,8 @@ def test_actnorm_data_init_pass(name, precision):
 
 
 def test_actnorm_init_rules():
-    """eval() never initialises (ActNorms.py:31-32); a non-zero bias only flips ``inited`` (:33-35); the reverse
-    path refuses un-initialised layers in train() mode instead of guessing."""
+    """eval() never initialises (ActNorms.py:31-32); a non-zero bias only flips ``inited`` (:33-35), on either path; the
+    reverse path refuses genuinely un-initialised (zero-bias) layers in train() mode instead of guessing."""
     from hcflow_amd import HCFlowNet_SR
     cfg = preset("SR_4X_tiny")
     p = cached_params("SR_4X_tiny", 11)
@@ -221,11 +221,21 @@ def test_actnorm_init_rules():
         net(hr=hr, lr=lr, reverse=False)
         assert not any(m.inited for m in an)                       # eval: untouched, still un-initialised
         net.train()
-        with pytest.raises(NotImplementedError):
-            net(lr=lr, eps_std=0.5, reverse=True)
-        net(hr=hr, lr=lr, reverse=False)                           # biases are non-zero: flags flip, values stay
+        out = net(lr=lr, eps_std=0.5, reverse=True, seed=1)        # non-zero biases: the reference only flips the flags
+        assert all(m.inited for m in an) and bool(torch.isfinite(out).all())
+        for m in an:
+            m.inited = False
+        net(hr=hr, lr=lr, reverse=False)                           # same on the forward path: flags flip, values stay
     assert all(m.inited for m in an)
     assert all(torch.equal(m.bias, b) for m, b in zip(an, before))
+    # genuinely un-initialised layers (zero bias) on the REVERSE path in train() mode: refused, not guessed
+    with torch.no_grad():
+        an[0].bias.zero_()
+        net.invalidate()
+        for m in an:
+            m.inited = False
+        with pytest.raises(NotImplementedError):
+            net(lr=lr, eps_std=0.5, reverse=True)
 
 
 # ---- BASELINE.json's full-size configurations, through size-independent properties ------------------------------

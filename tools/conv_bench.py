@@ -31,8 +31,8 @@ def main():
     ap.add_argument("--precision", default="exact", choices=["exact", "f16x3"])
     ap.add_argument("--ablate", type=int, default=0,
                     help="experiment switches (hcf_debug_set_ablation): 1 / 2 16-row tile for the 32 / 64-channel kernel, "
-                         "32 also run the split16 LDS-DMA kernel and report max |diff| in the clk column "
-                         "(bits << 8: its timing ablations), 64 scalar epilogue")
+                         "64 scalar epilogue. Phase timers / the in-kernel clock need the measurement build: "
+                         "make -C hcflow_amd/csrc TIMERS=1 && HCFLOW_LIB=hcflow_amd/libhcflow_hip_timers.so python tools/conv_bench.py")
     args = ap.parse_args()
     lib = _lib.load()
     assert lib.hcf_op_set_precision(_lib.Engine.PRECISIONS[args.precision]) == 0
