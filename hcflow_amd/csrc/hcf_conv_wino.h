@@ -1,0 +1,694 @@
+// fp32-equivalent 3x3 convolution in Winograd F(2x2, 3x3) form on the f16 matrix cores (gfx950).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per 4x4 input patch d -> 2x2 outputs, summed over input channels in the
+//   transformed domain: 16 independent [32 oc x 16 ic] x [16 ic x 32 patches] products per chunk -> 2.25x fewer MFMAs than the
+//   direct form. Every product is the f16x3 split of hcf_conv_f16x3.hip (a_hi w_hi + a_hi w_lo + a_lo w_hi, fp32 accumulate),
+//   applied to the TRANSFORMED operands: U = G g G^T is formed in fp64 on the host and pre-split, V = B^T d B is formed in
+//   fp32 registers (entries 0, +-1: three additions) and split there. On the full-depth nets the deviation from an fp64
+//   evaluation equals plain fp32's (tools/winograd_precision_check.py: 3.1e-6 / 3.7e-6 / 4.4e-6 for x4 / x8 / rescaling).
+//
+// Why: profiles/r02_notes.md -- under dense random-data f16 MFMA this part delivers ~1.5 PFLOP/s whatever the tiling, i.e. the
+// direct form is capped at ~0.60 of the nominal 833 TFLOP/s-equivalent before any memory traffic; the only way past that is
+// fewer MFMAs per output. The price is VALU work (transform + split: ~3 instructions per transformed value) and SIMD issue
+// slots, which is what bounds this kernel (tools/micro/wino_tile.hip).
+//
+// Structure: 512 threads = 8 waves, ONE persistent block per CU; unit = 8 output rows x 32 columns x 32 output channels.
+//   wave (xi, tg): transform row xi = 0..3 of tile group tg = 0 / 1 (4 output rows x 32 columns = 32 patches = the MFMA N);
+//   it reads the 2 patch rows x 4 columns its row of B^T touches, forms V[xi][0..3] for 8 channels per lane (the MFMA B
+//   fragment layout: lane = (patch, k-half)), and accumulates M[xi][nu] in 4 accumulators. Operand roles are swapped as in
+//   hcf_conv_s16.h (A = weights): a lane ends up with 16 output channels of ONE patch.
+//   LDS: two stages of {10 x 34 halo pixels x 16 channels fp32 (16-byte slots XOR-swizzled inside each 256-byte bank row:
+//   conflict-free patch reads), 32 KB of transformed weights [pos][plane][k-half][32 oc][8]}, filled by global_load_lds
+//   one chunk ahead (the next unit's first chunk during the last chunk of the current one); one barrier per chunk.
+//   Epilogue: R[xi][b] = sum_nu M[xi][nu] A[nu][b] in registers, one exchange of R through LDS (64 KB), then wave
+//   (a, q-pair) = (xi >> 1, xi & 1) forms Y[a][b] = sum_xi A^T[a][xi] R[xi][b] for 16 channels x 2 pixels per lane and stores
+//   16-byte vectors (bias / scale / activation / residuals as in the other conv kernels).
+// Sign folding: the wave computes t_j = d[r1][j] + sigma d[r2][j] and V_2 = t_1 - t_2, i.e. rows / columns 2 negated; the pack
+// negates U[2][.] and U[.][2] accordingly, so M is the true product.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <type_traits>
+#include <vector>
+
+namespace hcf {
+namespace wino {
+
+constexpr int TW = 32, TH = 8, HWP = TW + 2, HHP = TH + 2;
+constexpr int A_REAL_PIECES = HHP * HWP * 4;      // 1 360 16-byte pieces (340 pixels x 4 parts)
+constexpr int A_BYTES = 22 * 1024;                // 22 DMA instructions (48 dead pieces)
+constexpr int W_BYTES = 16 * 2 * 2 * 32 * 16;     // 32 768: [pos][plane][k-half][32 oc][8 halves]
+constexpr int STAGE = A_BYTES + W_BYTES;          // 55 296 = 54 DMA instructions
+constexpr int X_BYTES = 10240;                    // with the free stage: the 64 KB exchange buffer of the epilogue
+constexpr int S0_OFF = 0, X_OFF = STAGE, S1_OFF = STAGE + X_BYTES, TAB_OFF = S1_OFF + STAGE;
+constexpr int LDS_BYTES = TAB_OFF + 512;          // 121 344
+constexpr float UNSPLIT = 1.f / 2048.f;
+
+struct Src { const float* p; int cs, c0, n; };   // fp32 NHWC window [c0, c0 + n), n % 16 == 0, cs % 4 == 0, c0 % 4 == 0
+struct Args {
+  Src src[3];
+  int nsrc;
+  int B, H, W;
+  const char* wpack;       // [ntile_n][nchunk][W_BYTES] (+ one zero chunk), pack_weights_wino
+  int nchunk, ntile_n;
+  const float* bias;       // [32 * ntile_n]
+  const float* scale;
+  int act;                 // 0 none, 1 relu, 2 leaky relu 0.2
+  float* out; int out_cs, out_c0, cout;
+  const float* res1; int res1_cs, res1_c0; float rs1;      // y = res2 + rs2 * (res1 + rs1 * act((acc + bias) * scale))
+  const float* res2; int res2_cs, res2_c0; float rs2;
+  int* ovf;
+  const char* zeros;       // >= 64 bytes of zeros
+  unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
+};
+
+// w: PyTorch [cout][cin][3][3] (cin = sum of the source widths, each a multiple of 16). U = G g G^T in double, rows and
+// columns 2 negated, plane 0 = f16(U) * 2^11, plane 1 = f16((U - f16(U)) * 2^11).
+static inline bool pack_weights_wino(const float* w, int cin, int cout, std::vector<uint16_t>& pk) {
+  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  const int nchunk = cin / 16, ntn = (cout + 31) / 32;
+  pk.assign(((size_t)ntn * nchunk + 1) * (W_BYTES / 2), 0);
+  for (int oc = 0; oc < cout; ++oc)
+    for (int ic = 0; ic < cin; ++ic) {
+      const float* g = w + ((size_t)oc * cin + ic) * 9;
+      double t[4][3], U[4][4];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+      const int nt = oc >> 5, n = oc & 31, c = ic >> 4, h = (ic >> 3) & 1, e = ic & 7;
+      for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu) {
+          const double u = U[xi][nu] * ((xi == 2) ? -1.0 : 1.0) * ((nu == 2) ? -1.0 : 1.0);
+          const float x = (float)u;
+          if (!(fabsf(x) * 2048.f < 60000.f)) return false;
+          const _Float16 hi = (_Float16)x;
+          const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((float)((u - (double)(float)hi) * 2048.0));
+          const size_t o = ((size_t)(nt * nchunk + c) * W_BYTES) / 2 + (size_t)(((xi * 4 + nu) * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
+          memcpy(&pk[o], &p0, 2);
+          memcpy(&pk[o + 512], &p1, 2);
+        }
+    }
+  return true;
+}
+
+#if defined(__HIPCC__)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef const char __attribute__((address_space(1)))* gcptr;
+typedef __attribute__((address_space(3))) void* lptr;
+
+__device__ __forceinline__ int xcd_remap(int orig, int n) {
+  const int xcd = orig & 7, q = n >> 3, r = n & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+__device__ __forceinline__ gcptr uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (gcptr)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16(gcptr g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lptr)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float act1(float v, float slope, float lo) { return !(v <= 0.f) ? v : slope * fmaxf(v, lo); }
+// byte offset of (halo pixel px, 16-byte part) inside the activation region
+__device__ __forceinline__ int a_off(int px, int part) {
+  const int R = px >> 2, sl = (px & 3) * 4 + part;
+#if defined(WINO_ABL) && (WINO_ABL & 4)
+  return R * 256 + (sl << 4);
+#endif
+  return R * 256 + ((sl ^ ((R & 7) << 1)) << 4);
+}
+
+template <int RES>
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const Args a, const int nunits) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xi = wave & 3, tg = wave >> 2;
+  const int H = a.H, W = a.W, ntn = a.ntile_n, nchunk = a.nchunk;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+
+  // ---- DMA slots: instruction I = 8 j + wave (j = 0..6, I < 54) moves pieces [64 I, 64 I + 64) of the stage; I < 22:
+  // activation pieces (piece -> swizzled (pixel, part)), else weight pieces. Waves 0..5: j = 0..2 activations, 3..6 weights;
+  // waves 6, 7: j = 0, 1 activations, 2..5 weights.
+  const int na = (wave < 6) ? 3 : 2;
+  int adesc0, adesc1, adesc2;   // (hy << 16) | (hx << 8) | part * 16, or -1: dead piece
+  auto mk_adesc = [&](int j) {
+    const int pa = (8 * j + wave) * 64 + lane;
+#if defined(WINO_ABL) && (WINO_ABL & 4)
+    const int R = pa >> 4, sl = (pa & 15);
+#else
+    const int R = pa >> 4, sl = (pa & 15) ^ ((R & 7) << 1);
+#endif
+    const int px = R * 4 + (sl >> 2), part = sl & 3;
+    const int hy = px / HWP, hx = px - hy * HWP;
+    return (px < HHP * HWP) ? ((hy << 16) | (hx << 8) | (part << 4)) : -1;
+  };
+  adesc0 = mk_adesc(0); adesc1 = mk_adesc(1); adesc2 = mk_adesc(2);
+  const gcptr wq = uniform_ptr(a.wpack);
+  const gcptr zpage = uniform_ptr(a.zeros);
+  const int k0 = __builtin_amdgcn_readfirstlane(a.src[0].n >> 4);
+  const int k1 = k0 + __builtin_amdgcn_readfirstlane(a.nsrc > 1 ? (a.src[1].n >> 4) : 0);
+  const gcptr sp0 = uniform_ptr(a.src[0].p + a.src[0].c0);
+  const gcptr sp1 = uniform_ptr(a.nsrc > 1 ? a.src[1].p + a.src[1].c0 : a.src[0].p);
+  const gcptr sp2 = uniform_ptr(a.nsrc > 2 ? a.src[2].p + a.src[2].c0 : a.src[0].p);
+  const int csb0 = __builtin_amdgcn_readfirstlane(a.src[0].cs) * 4, csb1 = __builtin_amdgcn_readfirstlane(a.src[1].cs) * 4,
+            csb2 = __builtin_amdgcn_readfirstlane(a.src[2].cs) * 4;
+  const int woff = ((8 * 2 + wave - 22) * 64 + lane) * 16;      // weight-block byte offset of slot j = 2 seen as a weight slot
+
+  // DMA cursor: unit coordinates + chunk index of the NEXT chunk to fetch
+  int upix0 = -1, upix1 = -1, upix2 = -1;   // pixel index in the image of this thread's activation pieces, -1: zero padding / dead
+  int ub = 0, uy0 = 0, ux0 = 0, unt = 0, uc = 0;
+#define WINO_SETUP_UNIT(U)                                                                         \
+  {                                                                                                \
+    const int v_ = xcd_remap((U), nunits);                                                         \
+    unt = __builtin_amdgcn_readfirstlane(v_ % ntn);                                                \
+    const int t_ = v_ / ntn;                                                                       \
+    ux0 = __builtin_amdgcn_readfirstlane((t_ % tiles_x) * TW);                                     \
+    uy0 = __builtin_amdgcn_readfirstlane(((t_ / tiles_x) % tiles_y) * TH);                         \
+    ub = __builtin_amdgcn_readfirstlane(t_ / (tiles_x * tiles_y));                                 \
+    uc = 0;                                                                                        \
+    { const int y = uy0 + (adesc0 >> 16) - 1, x = ux0 + ((adesc0 >> 8) & 255) - 1;                 \
+      upix0 = (adesc0 >= 0 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : -1; }   \
+    { const int y = uy0 + (adesc1 >> 16) - 1, x = ux0 + ((adesc1 >> 8) & 255) - 1;                 \
+      upix1 = (adesc1 >= 0 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : -1; }   \
+    { const int y = uy0 + (adesc2 >> 16) - 1, x = ux0 + ((adesc2 >> 8) & 255) - 1;                 \
+      upix2 = (adesc2 >= 0 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : -1; }   \
+  }
+#if defined(WINO_ABL) && (WINO_ABL & 1)
+#define WINO_A_SRC(J, UPIX, ADESC) (wq + (J) * 1024 + lane * 16)
+#else
+#define WINO_A_SRC(J, UPIX, ADESC) (((UPIX) >= 0) ? sp_ + (size_t)(unsigned)(UPIX) * csb_ + ((ADESC) & 255) : zpage + ((ADESC) & 48))
+#endif
+  // fetch chunk uc of the cursor's unit into stage STG, advance the cursor. Straight-line code: 7 DMA instructions (6 for waves 6, 7)
+#define WINO_ISSUE_CHUNK(STG)                                                                      \
+  {                                                                                                \
+    char* const sbase_ = lds + ((STG) ? S1_OFF : S0_OFF) + wave * 1024;                            \
+    const bool in0_ = uc < k0, in1_ = uc < k1;                                                     \
+    const gcptr sp_ = (in0_ ? sp0 : in1_ ? sp1 : sp2) + (size_t)(in0_ ? uc : in1_ ? uc - k0 : uc - k1) * 64; \
+    const unsigned csb_ = in0_ ? csb0 : in1_ ? csb1 : csb2;                                        \
+    const gcptr wb_ = wq + ((size_t)unt * nchunk + uc) * W_BYTES + woff;                           \
+    glds16(WINO_A_SRC(0, upix0, adesc0), sbase_);                                                  \
+    glds16(WINO_A_SRC(1, upix1, adesc1), sbase_ + 8192);                                           \
+    glds16((na == 3) ? WINO_A_SRC(2, upix2, adesc2) : wb_, sbase_ + 2 * 8192);                     \
+    glds16(wb_ + 8192, sbase_ + 3 * 8192);                                                         \
+    glds16(wb_ + 2 * 8192, sbase_ + 4 * 8192);                                                     \
+    glds16(wb_ + 3 * 8192, sbase_ + 5 * 8192);                                                     \
+    if (na == 3) glds16(wb_ + 4 * 8192, sbase_ + 6 * 8192);                                        \
+    ++uc;                                                                                          \
+  }
+  // ---- fragment read offsets ----------------------------------------------------------------------------------------
+  // patch rows of transform row xi: B^T = (1,0,-1,0), (0,1,1,0), (0,-1,1,0), (0,1,0,-1)
+  const int r1 = (xi == 0) ? 0 : 1, r2 = (xi == 3) ? 3 : 2;
+  const float sigma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (xi == 1) ? 1.f : -1.f)));
+  const int trow = li >> 4, tcol = li & 15;
+  int poff[2][4];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) poff[rr][j] = a_off((4 * tg + 2 * trow + (rr ? r2 : r1)) * HWP + 2 * tcol + j, 2 * half);
+  const int fw = A_BYTES + (xi * 4 * 4 + half) * 512 + li * 16;      // + (nu * 4 + plane * 2) * 512
+
+  if (tid < 64) {       // y = act((acc / 2^11 + bias) * scale) = act(acc * ms + bs)
+    const float sc_ = (tid < 32 * ntn) ? a.scale[tid] : 1.f, bi_ = (tid < 32 * ntn) ? a.bias[tid] : 0.f;
+    reinterpret_cast<float*>(lds + TAB_OFF)[tid] = bi_ * sc_;
+    reinterpret_cast<float*>(lds + TAB_OFF)[64 + tid] = sc_ * UNSPLIT;
+  }
+
+#if defined(WINO_PROF)
+  unsigned long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pw_t0 = __builtin_readcyclecounter();
+#endif
+  int u = blockIdx.x;
+  if (u >= nunits) return;
+  WINO_SETUP_UNIT(u)
+  WINO_ISSUE_CHUNK(0)
+  int g = 0;
+  const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+  const float alo_ = (slope == 0.f) ? -3.0e38f : -INFINITY;
+
+  while (true) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    const int eb = ub, ey0 = uy0, ex0 = ux0, ent = unt;
+    const int un = u + gridDim.x;
+
+    for (int c = 0; c < nchunk; ++c, ++g) {
+      const int stg = g & 1;
+#if defined(WINO_PROF)
+      const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(WINO_PROF)
+      const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
+      __builtin_amdgcn_s_barrier();
+#if defined(WINO_PROF)
+      const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
+      if (c + 1 == nchunk) {               // the cursor moves on to the next unit (or idles on the zero page)
+        if (un < nunits) WINO_SETUP_UNIT(un)
+        else { upix0 = upix1 = upix2 = -1; uc = 0; unt = 0; }
+      }
+      if (stg) WINO_ISSUE_CHUNK(0) else WINO_ISSUE_CHUNK(1)
+#if defined(WINO_PROF)
+      const unsigned long long q3 = __builtin_readcyclecounter();
+      pw[0] += q1 - q0; pw[1] += q2 - q1; pw[5] += q3 - q2;
+#endif
+      const char* const sb = lds + (stg ? S1_OFF : S0_OFF);
+      // raw patch pixels: 2 rows x 4 columns x 8 channels
+      f32x4 d[2][4][2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d[rr][j][0] = *reinterpret_cast<const f32x4*>(sb + poff[rr][j]);
+          d[rr][j][1] = *reinterpret_cast<const f32x4*>(sb + (poff[rr][j] ^ 16));
+        }
+      f16x8 vh[4], vl[4];
+      {
+        float t[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[j][k] = __builtin_fmaf(sigma, d[1][j][k >> 2][k & 3], d[0][j][k >> 2][k & 3]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v[4] = {t[0][k] - t[2][k], t[1][k] + t[2][k], t[1][k] - t[2][k], t[1][k] - t[3][k]};
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const _Float16 h = (_Float16)v[p];
+            vh[p][k] = h;
+            vl[p][k] = (_Float16)(v[p] - (float)h);
+          }
+        }
+      }
+#if defined(WINO_PROF)
+      asm volatile("" :: "v"(vh[0][0]), "v"(vl[3][7]));
+      pw[6] += __builtin_readcyclecounter() - q3;
+#endif
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f16x8 w1 = *reinterpret_cast<const f16x8*>(sb + fw + (p * 4) * 512);
+        const f16x8 w2 = *reinterpret_cast<const f16x8*>(sb + fw + (p * 4 + 2) * 512);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, vh[p], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, vh[p], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, vl[p], acc[p], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue of unit (eb, ey0, ex0, ent) ---------------------------------------------------------------------------
+#if defined(WINO_PROF)
+    const unsigned long long qe0 = __builtin_readcyclecounter();
+#endif
+    {
+      float chk = 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) chk = fmaf(acc[p][r], 0.f, chk);
+      if (__any(chk != chk)) {
+        if (lane == 0) atomicOr(a.ovf, 1);
+      }
+    }
+#if defined(WINO_ABL) && (WINO_ABL & 2)
+    if (acc[0][0] == 123.456f) a.out[0] = acc[1][1] + acc[2][2] + acc[3][3];
+    u = un;
+    if (u >= nunits) break;
+    continue;
+#endif
+    // R[b] = sum_nu M[xi][nu] A[nu][b]:  R0 = M0 + M1 + M2,  R1 = M1 - M2 - M3
+    // exchange buffer (free stage + X): [tg][xi][b][q][lane] 16-byte pieces
+    char* const xb = lds + ((g & 1) ? S0_OFF : X_OFF);       // stage g & 1 is receiving the next chunk; the other one (+ X) is free
+    __builtin_amdgcn_s_barrier();                             // every wave is done reading the free stage
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 r0, r1_;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        r0[e] = acc[0][r] + acc[1][r] + acc[2][r];
+        r1_[e] = acc[1][r] - acc[2][r] - acc[3][r];
+      }
+      *reinterpret_cast<f32x4*>(xb + ((((tg * 4 + xi) * 2 + 0) * 4 + q) * 64 + lane) * 16) = r0;
+      *reinterpret_cast<f32x4*>(xb + ((((tg * 4 + xi) * 2 + 1) * 4 + q) * 64 + lane) * 16) = r1_;
+    }
+    __builtin_amdgcn_s_barrier();
+    // wave (a, qp) = (xi >> 1, xi & 1): output row 2 trow + a of the patch, channel quarters q = 2 qp, 2 qp + 1, both columns b
+    {
+      const int oa = xi >> 1, qp = xi & 1;
+      const int y = ey0 + 4 * tg + 2 * trow + oa;
+      const int cb = ent * 32 + 4 * half;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int x = ex0 + 2 * tcol + b;
+        const bool ok = y < H && x < W;
+        const size_t pix = (size_t)((size_t)eb * H + (y < H ? y : H - 1)) * W + (x < W ? x : W - 1);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * qp + qq;
+          auto R = [&](int x_) { return *reinterpret_cast<const f32x4*>(xb + ((((tg * 4 + x_) * 2 + b) * 4 + q) * 64 + lane) * 16); };
+          const f32x4 ra = R(oa ? 1 : 0), rb = R(oa ? 2 : 1), rc = R(oa ? 3 : 2);
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + (cb + 8 * q) * 4);
+          const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + 256 + (cb + 8 * q) * 4);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yv = oa ? (ra[e] - rb[e] - rc[e]) : (ra[e] + rb[e] + rc[e]);     // Y1 = R1 - R2 - R3, Y0 = R0 + R1 + R2
+            float t = fmaf(yv, ms[e], bs[e]);
+            t = act1(t, slope, alo_);
+            v[e] = t;
+          }
+          if (RES >= 1) {
+            const f32x4 r1v = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb + 8 * q);
+            v = v * a.rs1 + r1v;
+          }
+          if (RES == 2) {
+            const f32x4 r2v = *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb + 8 * q);
+            v = v * a.rs2 + r2v;
+          }
+          if (ok && cb + 8 * q < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb + 8 * q) = v;
+        }
+      }
+    }
+#if defined(WINO_PROF)
+    pw[3] += __builtin_readcyclecounter() - qe0;
+#endif
+    u = un;
+    if (u >= nunits) break;
+  }
+#undef WINO_SETUP_UNIT
+#undef WINO_ISSUE_CHUNK
+#undef WINO_A_SRC
+#if defined(WINO_PROF)
+  if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
+    atomicAdd(a.dbg + 0, pw[0]); atomicAdd(a.dbg + 1, pw[1]); atomicAdd(a.dbg + 2, __builtin_readcyclecounter() - pw_t0);
+    atomicAdd(a.dbg + 3, pw[3]); atomicAdd(a.dbg + 4, 1ull); atomicAdd(a.dbg + 5, pw[5]); atomicAdd(a.dbg + 6, pw[6]);
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: ONE wave per SIMD (256 threads, launch bound 1 wave / SIMD -> 512 registers per lane: the 16 position accumulators of a
+// wave live in the AGPR half). Wave w owns tile group w (output rows 4 w .. 4 w + 3 of a 16 x 32 unit) and ALL 16 transform
+// positions of its 32 patches, so (i) every patch pixel is read from LDS once (not once per transform row), (ii) the output
+// transform is done in registers -- no exchange through LDS, no epilogue barrier -- and (iii) the 32 KB weight chunk is shared
+// by 512 output pixels. Staging by buffer_load ... lds: SGPR resource + 32-bit offsets, conv zero padding = an out-of-range
+// offset (the hardware writes zeros), no per-lane 64-bit address arithmetic.
+namespace v2 {
+constexpr int TH2 = 16, HH2 = TH2 + 2;
+constexpr int A2_REAL = HH2 * HWP * 4;            // 2 448 pieces
+constexpr int A2_BYTES = 39 * 1024;               // 39 DMA instructions (48 dead pieces)
+constexpr int STAGE2 = A2_BYTES + W_BYTES;        // 72 704 = 71 instructions
+constexpr int TAB2_OFF = 2 * STAGE2;
+constexpr int LDS2_BYTES = TAB2_OFF + 512;        // 145 920
+constexpr int OOB = 0x7ffffff0;                   // beyond num_records of every tensor (launcher: tensors < 2^31 - 4096 bytes)
+constexpr int ROWB = HWP * 64;                    // 2 176 bytes per halo row
+// byte offset of (halo row, column x, 16-byte part): rows are affine (row * ROWB), the swizzle depends on the column only, so a
+// lane needs ONE base register per patch column and reaches the patch rows through immediates
+__host__ __device__ constexpr int a2_off(int row, int x, int part) {
+  return row * ROWB + (x >> 2) * 256 + (((((x & 3) * 4 + part)) ^ (((x >> 2) & 7) << 1)) << 4);
+}
+}  // namespace v2
+
+template <int RES>
+__global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const int nunits) {
+  using namespace v2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, ntn = a.ntile_n, nchunk = a.nchunk;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH2 - 1) / TH2;
+
+  // DMA slots: instruction I = 4 j + wave (j = 0..17, I < 71); I < 39 activation pieces, else weight pieces.
+  // wave < 3: j = 0..9 activations, 10..17 weights; wave 3: j = 0..8 activations, 9..16 weights.
+  const bool w3 = (wave == 3);
+  int upix[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) upix[j] = -1;
+  // piece (4 j + wave) * 64 + lane sits in 256-byte row R = (4 j + wave) * 4 + (lane >> 4), physical slot lane & 15;
+  // logical slot = physical ^ ((R & 7) << 1): part = its low 2 bits does not depend on j, pixel-in-row = its high 2 bits does
+  int part16[10];
+#pragma unroll
+  for (int j = 0; j < 10; ++j) {
+    const int pa_ = (4 * j + wave) * 64 + lane, hy_ = (pa_ * 241) >> 15, q_ = pa_ - hy_ * 136, m_ = q_ >> 4;
+    part16[j] = (((q_ & 15) ^ ((m_ & 7) << 1)) & 3) << 4;
+  }
+  const int k0 = __builtin_amdgcn_readfirstlane(a.src[0].n >> 4);
+  const int k1 = k0 + __builtin_amdgcn_readfirstlane(a.nsrc > 1 ? (a.src[1].n >> 4) : 0);
+  const long long npx = (long long)a.B * H * W;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, (int)(npx * a.src[0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[a.nsrc > 1 ? 1 : 0].p, 0, (int)(npx * a.src[a.nsrc > 1 ? 1 : 0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[a.nsrc > 2 ? 2 : 0].p, 0, (int)(npx * a.src[a.nsrc > 2 ? 2 : 0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, (ntn * nchunk + 1) * W_BYTES, 0x00020000);
+  const int csb0 = __builtin_amdgcn_readfirstlane(a.src[0].cs) * 4, csb1 = __builtin_amdgcn_readfirstlane(a.src[1].cs) * 4,
+            csb2 = __builtin_amdgcn_readfirstlane(a.src[2].cs) * 4;
+  const int cb0 = __builtin_amdgcn_readfirstlane(a.src[0].c0) * 4, cb1 = __builtin_amdgcn_readfirstlane(a.src[1].c0) * 4,
+            cb2 = __builtin_amdgcn_readfirstlane(a.src[2].c0) * 4;
+  const int wvo = lane * 16;                     // weight pieces: instruction I covers bytes [(I - 39) * 1024, + 1024) of the chunk
+
+  int ub = 0, uy0 = 0, ux0 = 0, unt = 0, uc = 0;   // DMA cursor
+#define W2_SETUP_UNIT(U)                                                                           \
+  {                                                                                                \
+    const int v_ = xcd_remap((U), nunits);                                                         \
+    unt = __builtin_amdgcn_readfirstlane(v_ % ntn);                                                \
+    const int t_ = v_ / ntn;                                                                       \
+    ux0 = __builtin_amdgcn_readfirstlane((t_ % tiles_x) * TW);                                     \
+    uy0 = __builtin_amdgcn_readfirstlane(((t_ / tiles_x) % tiles_y) * TH2);                        \
+    ub = __builtin_amdgcn_readfirstlane(t_ / (tiles_x * tiles_y));                                 \
+    uc = 0;                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 10; ++j) {                                               \
+      const int pa_ = (4 * j + wave) * 64 + lane;          /* piece = row * 136 + m * 16 + physical slot */ \
+      const int hy_ = (pa_ * 241) >> 15;                   /* pa / 136 for pa < 2700 */             \
+      const int q_ = pa_ - hy_ * 136, m_ = q_ >> 4;                                                \
+      const int hx_ = m_ * 4 + ((((q_ & 15) ^ ((m_ & 7) << 1))) >> 2);                             \
+      const int y = uy0 + hy_ - 1, x = ux0 + hx_ - 1;                                              \
+      upix[j] = (hy_ < HH2 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : -1;     \
+    }                                                                                              \
+  }
+#define W2_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
+  // activation slot J of the cursor's chunk (source SRC_ selected per chunk, wave-uniform)
+#define W2_A_SLOT(J, DST)                                                                          \
+  {                                                                                                \
+    const int vo_ = (upix[J] >= 0) ? (int)__umul24((unsigned)upix[J], (unsigned)csb_) + part16[J] : OOB; \
+    W2_DMA(rsa_, vo_, so_, DST);                                                                   \
+  }
+  // slots [J0, J1) of chunk uc of the cursor's unit -> stage STG (J1 = 18 ends the chunk: the cursor advances)
+#define W2_ISSUE(J0, J1, STG)                                                                      \
+  {                                                                                                \
+    char* const sb_ = lds + (STG) * STAGE2 + wave * 1024;                                          \
+    const int sidx_ = (uc < k0) ? 0 : (uc < k1) ? 1 : 2;                                           \
+    const int csb_ = sidx_ == 0 ? csb0 : sidx_ == 1 ? csb1 : csb2;                                 \
+    const __amdgpu_buffer_rsrc_t rsa_ = sidx_ == 0 ? rs0 : sidx_ == 1 ? rs1 : rs2;      /* scalar selects: no control flow around the DMA */ \
+    const int so_ = (sidx_ == 0 ? cb0 + uc * 64 : sidx_ == 1 ? cb1 + (uc - k0) * 64 : cb2 + (uc - k1) * 64); \
+    const int ws_ = (unt * nchunk + uc) * W_BYTES;                                                 \
+    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) {                                       \
+      if (j_ < 9) W2_A_SLOT(j_ < 10 ? j_ : 0, sb_ + j_ * 4096)                                     \
+      else if (j_ == 9) { if (!w3) W2_A_SLOT(9, sb_ + 9 * 4096) else W2_DMA(rsw, wvo, ws_, sb_ + 9 * 4096); } \
+      else if (j_ < 17) W2_DMA(rsw, wvo, ws_ + (4 * j_ + wave - 39) * 1024, sb_ + j_ * 4096);      \
+      else if (!w3) W2_DMA(rsw, wvo, ws_ + (4 * 17 + wave - 39) * 1024, sb_ + 17 * 4096);          \
+    }                                                                                              \
+    if ((J1) == 18) ++uc;                                                                          \
+  }
+
+  // fragment read offsets: patch pixel (row i, column j) of this lane's patch, part 2 half (the other part: ^ 16)
+  const int trow = li >> 4, tcol = li & 15;
+  int poff[4];                                   // patch column j, patch row 0; row i: + i * ROWB
+#pragma unroll
+  for (int j = 0; j < 4; ++j) poff[j] = a2_off(4 * wave + 2 * trow, 2 * tcol + j, 2 * half);
+  const int fw = A2_BYTES + half * 512 + li * 16;      // + ((pos * 2 + plane) * 2) * 512
+
+  if (tid < 64) {
+    const float sc_ = (tid < 32 * ntn) ? a.scale[tid] : 1.f, bi_ = (tid < 32 * ntn) ? a.bias[tid] : 0.f;
+    reinterpret_cast<float*>(lds + TAB2_OFF)[tid] = bi_ * sc_;
+    reinterpret_cast<float*>(lds + TAB2_OFF)[64 + tid] = sc_ * UNSPLIT;
+  }
+  int u = blockIdx.x;
+  if (u >= nunits) return;
+  W2_SETUP_UNIT(u)
+  W2_ISSUE(0, 18, 0)
+  int g = 0;
+  const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+  const float alo_ = (slope == 0.f) ? -3.0e38f : -INFINITY;
+
+  while (true) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    const int eb = ub, ey0 = uy0, ex0 = ux0, ent = unt;
+    const int un = u + gridDim.x;
+
+    for (int c = 0; c < nchunk; ++c, ++g) {
+      const int stg = g & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (c + 1 == nchunk) {
+        if (un < nunits) W2_SETUP_UNIT(un)
+        else {
+          uc = 0; unt = 0;
+#pragma unroll
+          for (int j = 0; j < 10; ++j) upix[j] = -1;
+        }
+      }
+      const char* const sb = lds + stg * STAGE2;
+      const int so = stg ^ 1;
+      // one transform row: t_j = ra_j + sg * rb_j (8 channels), V_nu, split, 4 positions x 3 MFMAs
+#define W2_XI(XI, RA, RB, SG)                                                                      \
+  {                                                                                                \
+    float t_[4][8];                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+      _Pragma("unroll") for (int k = 0; k < 8; ++k) t_[j][k] = RA[j][k >> 2][k & 3] + (SG) * RB[j][k >> 2][k & 3]; \
+    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                             \
+      f16x8 vh_, vl_;                                                                              \
+      _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                              \
+        const float v_ = (nu == 0) ? t_[0][k] - t_[2][k] : (nu == 1) ? t_[1][k] + t_[2][k] : (nu == 2) ? t_[1][k] - t_[2][k] : t_[1][k] - t_[3][k]; \
+        const _Float16 h_ = (_Float16)v_;                                                          \
+        vh_[k] = h_;                                                                               \
+        vl_[k] = (_Float16)(v_ - (float)h_);                                                       \
+      }                                                                                            \
+      const f16x8 w1_ = *reinterpret_cast<const f16x8*>(sb + fw + (((XI) * 4 + nu) * 4) * 512);    \
+      const f16x8 w2_ = *reinterpret_cast<const f16x8*>(sb + fw + (((XI) * 4 + nu) * 4 + 2) * 512); \
+      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, vh_, acc[(XI) * 4 + nu], 0, 0, 0); \
+      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2_, vh_, acc[(XI) * 4 + nu], 0, 0, 0); \
+      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, vl_, acc[(XI) * 4 + nu], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                           \
+    }                                                                                              \
+  }
+#define W2_LOAD_ROW(D, I)                                                                          \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+    D[j][0] = *reinterpret_cast<const f32x4*>(sb + poff[j] + (I) * ROWB);                          \
+    D[j][1] = *reinterpret_cast<const f32x4*>(sb + (poff[j] ^ 16) + (I) * ROWB);                   \
+  }
+      f32x4 da[4][2], db[4][2], dc[4][2];        // three patch rows live at most
+      W2_LOAD_ROW(da, 0)
+      W2_LOAD_ROW(dc, 2)
+      W2_ISSUE(0, 5, so)
+      W2_XI(0, da, dc, -1.f)                      // row 0 - row 2
+      __builtin_amdgcn_sched_barrier(0);
+      W2_LOAD_ROW(db, 1)
+      W2_ISSUE(5, 10, so)
+      W2_XI(1, db, dc, 1.f)                       // row 1 + row 2
+      __builtin_amdgcn_sched_barrier(0);
+      W2_ISSUE(10, 14, so)
+      W2_XI(2, db, dc, -1.f)                      // row 1 - row 2 (sign folded into the weights)
+      __builtin_amdgcn_sched_barrier(0);
+      W2_LOAD_ROW(da, 3)
+      W2_ISSUE(14, 18, so)
+      W2_XI(3, db, da, -1.f)                      // row 1 - row 3
+#undef W2_XI
+#undef W2_LOAD_ROW
+    }
+
+    // ---- epilogue: output transform in registers; lane (patch, half) holds channels (r&3) + 8 (r>>2) + 4 half -------------
+    {
+      float chk = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) chk = fmaf(acc[p][r], 0.f, chk);
+      if (__any(chk != chk)) {
+        if (lane == 0) atomicOr(a.ovf, 1);
+      }
+    }
+    const int cb = ent * 32 + 4 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + (cb + 8 * q) * 4);
+      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + (cb + 8 * q) * 4);
+      f32x4 y[2][2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        float R[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          R[x][0] = acc[x * 4 + 0][r] + acc[x * 4 + 1][r] + acc[x * 4 + 2][r];
+          R[x][1] = acc[x * 4 + 1][r] - acc[x * 4 + 2][r] - acc[x * 4 + 3][r];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          y[0][b][e] = R[0][b] + R[1][b] + R[2][b];
+          y[1][b][e] = R[1][b] - R[2][b] - R[3][b];
+        }
+      }
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int yy = ey0 + 4 * wave + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
+          const bool ok = yy < H && xx < W;
+          const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act1(fmaf(y[oa][b][e], ms[e], bs[e]), slope, alo_);
+          if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb + 8 * q);
+          if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb + 8 * q);
+          if (ok && cb + 8 * q < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb + 8 * q) = v;
+        }
+    }
+    u = un;
+    if (u >= nunits) break;
+  }
+#undef W2_SETUP_UNIT
+#undef W2_DMA
+#undef W2_A_SLOT
+#undef W2_ISSUE
+}
+
+static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2) {
+  if (a.nsrc < 1 || a.nsrc > 3 || !a.wpack || !a.bias || !a.scale || !a.ovf || !a.zeros || !a.out || a.nchunk < 1) return -1;
+  if (a.ntile_n < 1 || a.ntile_n > 2 || (a.cout & 3)) return -6;
+  int kt = 0;
+  for (int i = 0; i < a.nsrc; ++i) {
+    if (!a.src[i].p || (a.src[i].n & 15) || (a.src[i].cs & 3) || (a.src[i].c0 & 3) || (reinterpret_cast<uintptr_t>(a.src[i].p) & 15)) return -6;
+    if ((long long)a.B * a.H * a.W * a.src[i].cs * 4 >= 0x7fffe000LL) return -6;       // 31-bit byte offsets (out-of-range = padding)
+    kt += a.src[i].n >> 4;
+  }
+  if (kt != a.nchunk) return -1;
+  if (((a.out_cs | a.out_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out) & 15)) return -6;
+  if (a.res1 && (((a.res1_cs | a.res1_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res1) & 15))) return -6;
+  if (a.res2 && (((a.res2_cs | a.res2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res2) & 15))) return -6;
+  if (a.res2 && !a.res1) return -1;
+  if ((long long)a.B * a.H * a.W >= (1LL << 24)) return -6;                            // 24-bit pixel index (mul24)
+  const int th = (version == 2) ? v2::TH2 : TH;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + th - 1) / th;
+  const long long nunits = (long long)a.B * tiles_x * tiles_y * a.ntile_n;
+  if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
+  const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
+  static bool attr[2][3] = {{false, false, false}, {false, false, false}};
+  const int res = a.res2 ? 2 : a.res1 ? 1 : 0;
+  const int ldsb = (version == 2) ? v2::LDS2_BYTES : LDS_BYTES;
+  auto go = [&](auto fn, int threads) {
+    if (!attr[version == 2][res]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -2;
+      attr[version == 2][res] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), ldsb, st, a, (int)nunits);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  };
+  if (version == 2) {
+    if (res == 0) return go(conv_wino2_kernel<0>, 256);
+    if (res == 1) return go(conv_wino2_kernel<1>, 256);
+    return go(conv_wino2_kernel<2>, 256);
+  }
+  if (res == 0) return go(conv_wino_kernel<0>, 512);
+  if (res == 1) return go(conv_wino_kernel<1>, 512);
+  return go(conv_wino_kernel<2>, 512);
+}
+#endif  // __HIPCC__
+
+}  // namespace wino
+}  // namespace hcf
