@@ -47,6 +47,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// f16 hi / lo split of four fp32 values -> {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves. hi = RNE f16 (v_cvt_pk_f16_f32);
+// lo = f16(v - hi) in ONE instruction per value: the mixed-precision FMA reads hi as f16 and v as fp32 and writes its f16
+// result into one half of the destination (6 VALU per slot instead of 10, and none of them packed-fp32, which is slow
+// beside MFMAs -- MI355X_MICROARCH.md).
+__device__ __forceinline__ f32x4 split4(const f32x4 v) {
+  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
+  const uint32_t H0 = __builtin_bit_cast(uint32_t, h01), H1 = __builtin_bit_cast(uint32_t, h23);
+  uint32_t L0, L1;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L0) : "v"(H0), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L0) : "v"(H0), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L1) : "v"(H1), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L1) : "v"(H1), "v"(v.w));
+  f32x4 r;
+  r.x = __builtin_bit_cast(float, H0); r.y = __builtin_bit_cast(float, H1);
+  r.z = __builtin_bit_cast(float, L0); r.w = __builtin_bit_cast(float, L1);
+  return r;
+}
 // explicit global address space: a pointer rebuilt from SGPR halves would otherwise be "generic" and
 // its loads become flat_load, which also tick lgkmcnt and so serialise with every LDS wait
 typedef const float __attribute__((address_space(1)))* gfptr;
@@ -229,13 +247,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       v.z = (stg_valid > 2) ? v.z : 0.f;                                                          \
       v.w = 0.f;                                                                                  \
     }                                                                                             \
-    union { f16x4 h[2]; f32x4 f; } u_;                                                            \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-      const _Float16 h = (_Float16)v[e];                                                          \
-      u_.h[0][e] = h;                                                                             \
-      u_.h[1][e] = (_Float16)(v[e] - (float)h);                                                   \
-    }                                                                                             \
-    stg[S] = u_.f;                                                                                \
+    stg[S] = split4(v);                                                                           \
   }
 #define HCF_STAGE_SPLIT()                                                                         \
   { _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) HCF_SPLIT_SLOT(s) }

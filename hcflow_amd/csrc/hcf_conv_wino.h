@@ -400,12 +400,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const Args a, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// v2: ONE wave per SIMD (256 threads, launch bound 1 wave / SIMD -> 512 registers per lane: the 16 position accumulators of a
-// wave live in the AGPR half). Wave w owns tile group w (output rows 4 w .. 4 w + 3 of a 16 x 32 unit) and ALL 16 transform
-// positions of its 32 patches, so (i) every patch pixel is read from LDS once (not once per transform row), (ii) the output
-// transform is done in registers -- no exchange through LDS, no epilogue barrier -- and (iii) the 32 KB weight chunk is shared
-// by 512 output pixels. Staging by buffer_load ... lds: SGPR resource + 32-bit offsets, conv zero padding = an out-of-range
-// offset (the hardware writes zeros), no per-lane 64-bit address arithmetic.
+// v3: 16 x 32-pixel unit, 8 waves = 4 tile groups x 2 transform-row pairs, TWO waves per SIMD (256 registers per lane: the 8
+// position accumulators of a wave sit in the AGPR half). What the one-wave-per-SIMD experiment (v2, profiles/r02_notes.md)
+// showed: every instruction of a lone wave costs ~5 cycles of issue, an LDS-DMA piece 60-100, and nothing overlaps unless it
+// is hand-interleaved; with a partner wave on the SIMD the hardware interleaves the two streams by itself. Versus v1: the
+// 32 KB weight chunk is shared by 512 pixels (not 256), conflict-free 128-bit LDS reads (the XOR key covers all four slot
+// bits: a 16-lane group of a ds_read_b128 sees 16 distinct slots), the f16 hi / lo split costs 1.5 instructions per value
+// (v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16) instead of 3.5, no packed-fp32 VALU (slow beside MFMAs), staging by
+// buffer_load ... lds with an SGPR resource and 32-bit offsets (conv zero padding = an out-of-range offset: the hardware
+// writes zeros; no per-lane 64-bit address arithmetic).
 namespace v2 {
 constexpr int TH2 = 16, HH2 = TH2 + 2;
 constexpr int A2_REAL = HH2 * HWP * 4;            // 2 448 pieces
@@ -413,37 +416,56 @@ constexpr int A2_BYTES = 39 * 1024;               // 39 DMA instructions (48 dea
 constexpr int STAGE2 = A2_BYTES + W_BYTES;        // 72 704 = 71 instructions
 constexpr int TAB2_OFF = 2 * STAGE2;
 constexpr int LDS2_BYTES = TAB2_OFF + 512;        // 145 920
-constexpr int OOB = 0x7ffffff0;                   // beyond num_records of every tensor (launcher: tensors < 2^31 - 4096 bytes)
 constexpr int ROWB = HWP * 64;                    // 2 176 bytes per halo row
 // byte offset of (halo row, column x, 16-byte part): rows are affine (row * ROWB), the swizzle depends on the column only, so a
-// lane needs ONE base register per patch column and reaches the patch rows through immediates
+// lane needs ONE base register per patch column and reaches the patch rows through immediates / a scalar row offset
 __host__ __device__ constexpr int a2_off(int row, int x, int part) {
-  return row * ROWB + (x >> 2) * 256 + (((((x & 3) * 4 + part)) ^ (((x >> 2) & 7) << 1)) << 4);
+  return row * ROWB + (x >> 2) * 256 + (((((x & 3) * 4 + part)) ^ ((x >> 2) & 7)) << 4);
 }
 }  // namespace v2
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// f16 hi / lo split of 8 fp32 values: hi = RNE f16 pairs (v_cvt_pk_f16_f32), lo = f16(v - hi) by the mixed-precision FMA (one
+// instruction per value: reads hi as f16 and v as f32, writes the f16 result into one half of the destination register).
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& h, u32x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 hh = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+    h[i] = __builtin_bit_cast(uint32_t, hh);
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h[i]), "v"(v[2 * i]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h[i]), "v"(v[2 * i + 1]));
+    l[i] = lo;
+  }
+}
+
 template <int RES>
-__global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const int nunits) {
+__global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const int nunits) {
   using namespace v2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xp = wave & 1, tg = wave >> 1;       // transform rows 2 xp, 2 xp + 1 of tile group tg (output rows 4 tg .. 4 tg + 3)
   const int H = a.H, W = a.W, ntn = a.ntile_n, nchunk = a.nchunk;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH2 - 1) / TH2;
 
-  // DMA slots: instruction I = 4 j + wave (j = 0..17, I < 71); I < 39 activation pieces, else weight pieces.
-  // wave < 3: j = 0..9 activations, 10..17 weights; wave 3: j = 0..8 activations, 9..16 weights.
-  const bool w3 = (wave == 3);
-  int upix[10];
+  // DMA slots: instruction I = 8 j + wave (j = 0..8, I < 71); I < 39 activation pieces, else weight piece I - 39.
+  // j < 4: activations; j = 4: activations (wave 7: weight piece 0); j = 5..7: weights; j = 8: weights (wave 7: none).
+  const bool w7 = (wave == 7);
+  // global pixel index of activation slot j; padding / dead pieces: B H W, whose byte offset is exactly the end of the
+  // tensor for every source -> out of range -> the DMA writes zeros (no select on the issue path)
+  const int padpix = a.B * H * W;
+  int upix[5];
 #pragma unroll
-  for (int j = 0; j < 10; ++j) upix[j] = -1;
-  // piece (4 j + wave) * 64 + lane sits in 256-byte row R = (4 j + wave) * 4 + (lane >> 4), physical slot lane & 15;
-  // logical slot = physical ^ ((R & 7) << 1): part = its low 2 bits does not depend on j, pixel-in-row = its high 2 bits does
-  int part16[10];
+  for (int j = 0; j < 5; ++j) upix[j] = padpix;
+  // piece (8 j + wave) * 64 + lane sits in 256-byte row R = piece >> 4 at physical slot lane & 15; its logical slot (pixel in
+  // row, 16-byte part) = physical ^ key(R). The part bits of all j are packed into one register, at bits 4 + 2 j.
+  uint32_t partpk = 0;
 #pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const int pa_ = (4 * j + wave) * 64 + lane, hy_ = (pa_ * 241) >> 15, q_ = pa_ - hy_ * 136, m_ = q_ >> 4;
-    part16[j] = (((q_ & 15) ^ ((m_ & 7) << 1)) & 3) << 4;
+  for (int j = 0; j < 5; ++j) {
+    const int pa_ = (8 * j + wave) * 64 + lane, hy_ = (pa_ * 241) >> 15, q_ = pa_ - hy_ * 136, m_ = q_ >> 4;
+    partpk |= (uint32_t)(((q_ & 15) ^ (m_ & 7)) & 3) << (4 + 2 * j);
   }
   const int k0 = __builtin_amdgcn_readfirstlane(a.src[0].n >> 4);
   const int k1 = k0 + __builtin_amdgcn_readfirstlane(a.nsrc > 1 ? (a.src[1].n >> 4) : 0);
@@ -456,9 +478,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const 
             csb2 = __builtin_amdgcn_readfirstlane(a.src[2].cs) * 4;
   const int cb0 = __builtin_amdgcn_readfirstlane(a.src[0].c0) * 4, cb1 = __builtin_amdgcn_readfirstlane(a.src[1].c0) * 4,
             cb2 = __builtin_amdgcn_readfirstlane(a.src[2].c0) * 4;
-  const int wvo = lane * 16;                     // weight pieces: instruction I covers bytes [(I - 39) * 1024, + 1024) of the chunk
+  const int wvo = lane * 16;                     // weight piece q covers bytes [q * 1024, + 1024) of the chunk
 
   int ub = 0, uy0 = 0, ux0 = 0, unt = 0, uc = 0;   // DMA cursor
+  // (the lane index goes through an empty asm so that the per-slot row / column arithmetic is redone here, once per unit,
+  //  instead of being hoisted into loop-invariant registers that then spill)
 #define W2_SETUP_UNIT(U)                                                                           \
   {                                                                                                \
     const int v_ = xcd_remap((U), nunits);                                                         \
@@ -468,46 +492,63 @@ __global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const 
     uy0 = __builtin_amdgcn_readfirstlane(((t_ / tiles_x) % tiles_y) * TH2);                        \
     ub = __builtin_amdgcn_readfirstlane(t_ / (tiles_x * tiles_y));                                 \
     uc = 0;                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < 10; ++j) {                                               \
-      const int pa_ = (4 * j + wave) * 64 + lane;          /* piece = row * 136 + m * 16 + physical slot */ \
+    int ln_ = lane;                                                                                \
+    asm volatile("" : "+v"(ln_));                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                \
+      const int pa_ = (8 * j + wave) * 64 + ln_;           /* piece = row * 136 + m * 16 + physical slot */ \
       const int hy_ = (pa_ * 241) >> 15;                   /* pa / 136 for pa < 2700 */             \
       const int q_ = pa_ - hy_ * 136, m_ = q_ >> 4;                                                \
-      const int hx_ = m_ * 4 + ((((q_ & 15) ^ ((m_ & 7) << 1))) >> 2);                             \
+      const int hx_ = m_ * 4 + (((q_ & 15) ^ (m_ & 7)) >> 2);                                      \
       const int y = uy0 + hy_ - 1, x = ux0 + hx_ - 1;                                              \
-      upix[j] = (hy_ < HH2 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : -1;     \
+      upix[j] = (hy_ < HH2 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : padpix; \
     }                                                                                              \
   }
+#if defined(WINO_ABL) && (WINO_ABL & 8)     // ablation: no staging traffic (results are garbage)
+#define W2_DMA(RS, VOFF, SOFF, DST) asm volatile("" :: "v"(VOFF), "s"(SOFF))
+#else
 #define W2_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
-  // activation slot J of the cursor's chunk (source SRC_ selected per chunk, wave-uniform)
+#endif
+  // per-chunk scalars of the DMA cursor (source selected per chunk, wave-uniform; scalar selects: no control flow around a DMA)
+  int csb_ = 0, so_ = 0, ws_ = 0;
+  uint32_t pp_ = partpk;
+  __amdgpu_buffer_rsrc_t rsa_ = rs0;
+#define W2_CHUNK_SCALARS()                                                                         \
+  {                                                                                                \
+    const int sidx_ = (uc < k0) ? 0 : (uc < k1) ? 1 : 2;                                           \
+    csb_ = sidx_ == 0 ? csb0 : sidx_ == 1 ? csb1 : csb2;                                           \
+    rsa_ = sidx_ == 0 ? rs0 : sidx_ == 1 ? rs1 : rs2;                                              \
+    so_ = (sidx_ == 0 ? cb0 + uc * 64 : sidx_ == 1 ? cb1 + (uc - k0) * 64 : cb2 + (uc - k1) * 64); \
+    ws_ = (unt * nchunk + uc) * W_BYTES;                                                           \
+    pp_ = partpk;                                                                                  \
+    asm volatile("" : "+v"(pp_));           /* keeps the per-slot field extraction out of loop-invariant registers */ \
+  }
 #define W2_A_SLOT(J, DST)                                                                          \
   {                                                                                                \
-    const int vo_ = (upix[J] >= 0) ? (int)__umul24((unsigned)upix[J], (unsigned)csb_) + part16[J] : OOB; \
+    const int p16_ = (int)((pp_ >> (2 * (J))) & 0x30u);                                            \
+    const int vo_ = (int)__umul24((unsigned)upix[J], (unsigned)csb_) + p16_;                       \
     W2_DMA(rsa_, vo_, so_, DST);                                                                   \
   }
-  // slots [J0, J1) of chunk uc of the cursor's unit -> stage STG (J1 = 18 ends the chunk: the cursor advances)
+  // slots [J0, J1) of the cursor's chunk -> stage STG
 #define W2_ISSUE(J0, J1, STG)                                                                      \
   {                                                                                                \
     char* const sb_ = lds + (STG) * STAGE2 + wave * 1024;                                          \
-    const int sidx_ = (uc < k0) ? 0 : (uc < k1) ? 1 : 2;                                           \
-    const int csb_ = sidx_ == 0 ? csb0 : sidx_ == 1 ? csb1 : csb2;                                 \
-    const __amdgpu_buffer_rsrc_t rsa_ = sidx_ == 0 ? rs0 : sidx_ == 1 ? rs1 : rs2;      /* scalar selects: no control flow around the DMA */ \
-    const int so_ = (sidx_ == 0 ? cb0 + uc * 64 : sidx_ == 1 ? cb1 + (uc - k0) * 64 : cb2 + (uc - k1) * 64); \
-    const int ws_ = (unt * nchunk + uc) * W_BYTES;                                                 \
     _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) {                                       \
-      if (j_ < 9) W2_A_SLOT(j_ < 10 ? j_ : 0, sb_ + j_ * 4096)                                     \
-      else if (j_ == 9) { if (!w3) W2_A_SLOT(9, sb_ + 9 * 4096) else W2_DMA(rsw, wvo, ws_, sb_ + 9 * 4096); } \
-      else if (j_ < 17) W2_DMA(rsw, wvo, ws_ + (4 * j_ + wave - 39) * 1024, sb_ + j_ * 4096);      \
-      else if (!w3) W2_DMA(rsw, wvo, ws_ + (4 * 17 + wave - 39) * 1024, sb_ + 17 * 4096);          \
+      if (j_ < 4) W2_A_SLOT(j_ < 5 ? j_ : 0, sb_ + j_ * 8192)                                      \
+      else if (j_ == 4) { if (!w7) W2_A_SLOT(4, sb_ + 4 * 8192) else W2_DMA(rsw, wvo, ws_, sb_ + 4 * 8192); } \
+      else if (j_ < 8) W2_DMA(rsw, wvo, ws_ + (8 * j_ + wave - 39) * 1024, sb_ + j_ * 8192);       \
+      else if (!w7) W2_DMA(rsw, wvo, ws_ + (8 * 8 + wave - 39) * 1024, sb_ + 8 * 8192);            \
     }                                                                                              \
-    if ((J1) == 18) ++uc;                                                                          \
   }
 
   // fragment read offsets: patch pixel (row i, column j) of this lane's patch, part 2 half (the other part: ^ 16)
   const int trow = li >> 4, tcol = li & 15;
   int poff[4];                                   // patch column j, patch row 0; row i: + i * ROWB
 #pragma unroll
-  for (int j = 0; j < 4; ++j) poff[j] = a2_off(4 * wave + 2 * trow, 2 * tcol + j, 2 * half);
-  const int fw = A2_BYTES + half * 512 + li * 16;      // + ((pos * 2 + plane) * 2) * 512
+  for (int j = 0; j < 4; ++j) poff[j] = a2_off(4 * tg + 2 * trow, 2 * tcol + j, 2 * half);
+  // transform rows of this wave: xp = 0: t = r0 - r2, then r1 + r2; xp = 1: t = r1 - r2 (sign folded into the weights), then r1 - r3
+  const int rowP = xp ? ROWB : 0, rowS = xp ? 3 * ROWB : 2 * ROWB;     // first: row P - row 2; second: row 1 + sg * row S
+  const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xp ? -1.f : 1.f)));
+  const int fw = A2_BYTES + half * 512 + li * 16 + xp * (8 * 4 * 512);   // + ((local pos * 2 + plane) * 2) * 512
 
   if (tid < 64) {
     const float sc_ = (tid < 32 * ntn) ? a.scale[tid] : 1.f, bi_ = (tid < 32 * ntn) ? a.bias[tid] : 0.f;
@@ -516,16 +557,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const 
   }
   int u = blockIdx.x;
   if (u >= nunits) return;
+#if defined(WINO_PROF)
+  unsigned long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pw_t0 = __builtin_readcyclecounter();
+#endif
   W2_SETUP_UNIT(u)
-  W2_ISSUE(0, 18, 0)
+  W2_CHUNK_SCALARS()
+  W2_ISSUE(0, 9, 0)
+  ++uc;
   int g = 0;
   const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
-  const float alo_ = (slope == 0.f) ? -3.0e38f : -INFINITY;
 
   while (true) {
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     const int eb = ub, ey0 = uy0, ex0 = ux0, ent = unt;
@@ -533,119 +579,182 @@ __global__ __launch_bounds__(256, 1) void conv_wino2_kernel(const Args a, const 
 
     for (int c = 0; c < nchunk; ++c, ++g) {
       const int stg = g & 1;
+#if defined(WINO_PROF)
+      const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(WINO_PROF)
+      const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();
+#if defined(WINO_PROF)
+      const unsigned long long q2 = __builtin_readcyclecounter();
+      pw[0] += q1 - q0; pw[1] += q2 - q1;
+#endif
       if (c + 1 == nchunk) {
         if (un < nunits) W2_SETUP_UNIT(un)
         else {
           uc = 0; unt = 0;
 #pragma unroll
-          for (int j = 0; j < 10; ++j) upix[j] = -1;
+          for (int j = 0; j < 5; ++j) upix[j] = padpix;
         }
       }
+      W2_CHUNK_SCALARS()
       const char* const sb = lds + stg * STAGE2;
       const int so = stg ^ 1;
-      // one transform row: t_j = ra_j + sg * rb_j (8 channels), V_nu, split, 4 positions x 3 MFMAs
-#define W2_XI(XI, RA, RB, SG)                                                                      \
-  {                                                                                                \
-    float t_[4][8];                                                                                \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-      _Pragma("unroll") for (int k = 0; k < 8; ++k) t_[j][k] = RA[j][k >> 2][k & 3] + (SG) * RB[j][k >> 2][k & 3]; \
-    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                             \
-      f16x8 vh_, vl_;                                                                              \
-      _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                              \
-        const float v_ = (nu == 0) ? t_[0][k] - t_[2][k] : (nu == 1) ? t_[1][k] + t_[2][k] : (nu == 2) ? t_[1][k] - t_[2][k] : t_[1][k] - t_[3][k]; \
-        const _Float16 h_ = (_Float16)v_;                                                          \
-        vh_[k] = h_;                                                                               \
-        vl_[k] = (_Float16)(v_ - (float)h_);                                                       \
-      }                                                                                            \
-      const f16x8 w1_ = *reinterpret_cast<const f16x8*>(sb + fw + (((XI) * 4 + nu) * 4) * 512);    \
-      const f16x8 w2_ = *reinterpret_cast<const f16x8*>(sb + fw + (((XI) * 4 + nu) * 4 + 2) * 512); \
-      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, vh_, acc[(XI) * 4 + nu], 0, 0, 0); \
-      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2_, vh_, acc[(XI) * 4 + nu], 0, 0, 0); \
-      acc[(XI) * 4 + nu] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1_, vl_, acc[(XI) * 4 + nu], 0, 0, 0); \
-      __builtin_amdgcn_sched_barrier(0);                                                           \
-    }                                                                                              \
-  }
-#define W2_LOAD_ROW(D, I)                                                                          \
+#define W2_LOAD_ROW(D, OFF)                                                                        \
   _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-    D[j][0] = *reinterpret_cast<const f32x4*>(sb + poff[j] + (I) * ROWB);                          \
-    D[j][1] = *reinterpret_cast<const f32x4*>(sb + (poff[j] ^ 16) + (I) * ROWB);                   \
+    const f32x4 x0_ = *reinterpret_cast<const f32x4*>(sb + poff[j] + (OFF));                       \
+    const f32x4 x1_ = *reinterpret_cast<const f32x4*>(sb + (poff[j] ^ 16) + (OFF));                \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) { D[j][k] = x0_[k]; D[j][4 + k] = x1_[k]; }      \
   }
-      f32x4 da[4][2], db[4][2], dc[4][2];        // three patch rows live at most
-      W2_LOAD_ROW(da, 0)
-      W2_LOAD_ROW(dc, 2)
-      W2_ISSUE(0, 5, so)
-      W2_XI(0, da, dc, -1.f)                      // row 0 - row 2
-      __builtin_amdgcn_sched_barrier(0);
-      W2_LOAD_ROW(db, 1)
-      W2_ISSUE(5, 10, so)
-      W2_XI(1, db, dc, 1.f)                       // row 1 + row 2
-      __builtin_amdgcn_sched_barrier(0);
-      W2_ISSUE(10, 14, so)
-      W2_XI(2, db, dc, -1.f)                      // row 1 - row 2 (sign folded into the weights)
-      __builtin_amdgcn_sched_barrier(0);
-      W2_LOAD_ROW(da, 3)
-      W2_ISSUE(14, 18, so)
-      W2_XI(3, db, da, -1.f)                      // row 1 - row 3
+#define W2_V(NU, T, K) (((NU) == 0) ? T[0][K] - T[2][K] : ((NU) == 1) ? T[1][K] + T[2][K] : ((NU) == 2) ? T[1][K] - T[2][K] : T[1][K] - T[3][K])
+#if defined(WINO_ABL) && (WINO_ABL & 16)    // ablation: no matrix instructions
+#define W2_MFMA(P, WW, VX) asm volatile("" :: "v"(WW), "v"(VX));
+#else
+#define W2_MFMA(P, WW, VX) acc[P] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P], 0, 0, 0);
+#endif
+      // the four positions of local transform row I (t in T)
+#define W2_XI(I, T)                                                                                \
+  _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                               \
+    float v_[8];                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) v_[k] = W2_V(nu, T, k);                          \
+    u32x4 vh_, vl_;                                                                                \
+    split8(v_, vh_, vl_);                                                                          \
+    const f16x8 w1_ = *reinterpret_cast<const f16x8*>(sb + fw + (((I) * 4 + nu) * 4) * 512);       \
+    const f16x8 w2_ = *reinterpret_cast<const f16x8*>(sb + fw + (((I) * 4 + nu) * 4 + 2) * 512);   \
+    W2_MFMA((I) * 4 + nu, w1_, vh_)                                                                \
+    W2_MFMA((I) * 4 + nu, w2_, vh_)                                                                \
+    W2_MFMA((I) * 4 + nu, w1_, vl_)                                                                \
+  }
+      float t_[4][8];
+      {
+        float ra[4][8], rc[4][8];
+        W2_LOAD_ROW(ra, rowP)
+        W2_LOAD_ROW(rc, 2 * ROWB)
+        W2_ISSUE(0, 3, so)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t_[j][k] = ra[j][k] - rc[j][k];
+      }
+      W2_XI(0, t_)
+      W2_ISSUE(3, 6, so)
+      {
+        float ra[4][8], rc[4][8];
+        W2_LOAD_ROW(ra, ROWB)
+        W2_LOAD_ROW(rc, rowS)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t_[j][k] = fmaf(sg, rc[j][k], ra[j][k]);
+      }
+      W2_ISSUE(6, 9, so)
+      ++uc;
+      W2_XI(1, t_)
+#if defined(WINO_PROF)
+      pw[6] += __builtin_readcyclecounter() - q2;
+#endif
 #undef W2_XI
+#undef W2_MFMA
+#undef W2_V
 #undef W2_LOAD_ROW
     }
 
-    // ---- epilogue: output transform in registers; lane (patch, half) holds channels (r&3) + 8 (r>>2) + 4 half -------------
+    // ---- epilogue -----------------------------------------------------------------------------------------------------------
+    // In-wave: R[i][b] = sum_nu M[i][nu] A[nu][b]; the pair's partial outputs: xp 0: y0 = R0 + R1, y1 = R1; xp 1 (rows 2, 3):
+    // y0 = R0', y1 = -R0' - R1'. Wave xp finishes channel groups q = 2 xp, 2 xp + 1 (registers r = 4 q + e) and gets the
+    // partner's partials for them through LDS (the stage just consumed: 8 KB per wave).
+#if defined(WINO_PROF)
+    const unsigned long long qe0 = __builtin_readcyclecounter();
+#endif
+    float chk = 0.f;                               // Inf / NaN anywhere in the accumulators reaches a partial output
+    f32x4 mine[2][2][2];                           // [q local][a][b]
     {
-      float chk = 0.f;
+      char* const xb = lds + ((g - 1) & 1) * STAGE2 + tg * 16384 + (xp ^ 1) * 8192 + lane * 16;   // partner's inbox
+      __builtin_amdgcn_s_barrier();                // every wave is done reading the stage
 #pragma unroll
-      for (int p = 0; p < 16; ++p)
+      for (int q = 0; q < 4; ++q) {
+        f32x4 y[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) chk = fmaf(acc[p][r], 0.f, chk);
-      if (__any(chk != chk)) {
-        if (lane == 0) atomicOr(a.ovf, 1);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          float R[2][2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            R[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+            R[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            y[0][b][e] = xp ? R[0][b] : R[0][b] + R[1][b];
+            y[1][b][e] = xp ? -R[0][b] - R[1][b] : R[1][b];
+            chk = fmaf(y[0][b][e], 0.f, chk);
+            chk = fmaf(y[1][b][e], 0.f, chk);
+          }
+        }
+        const bool keep = (q >> 1) == xp;
+        if (keep) {
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) mine[q & 1][aa][b] = y[aa][b];
+        } else {
+#pragma unroll
+          for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(xb + (((q & 1) * 2 + aa) * 2 + b) * 1024) = y[aa][b];
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    {
+      const char* const ib = lds + ((g - 1) & 1) * STAGE2 + tg * 16384 + xp * 8192 + lane * 16;
+#pragma unroll
+      for (int ql = 0; ql < 2; ++ql) {
+        const int cb = ent * 32 + 4 * half + 8 * (2 * xp + ql);
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + cb * 4);
+        const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + cb * 4);
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const f32x4 other = *reinterpret_cast<const f32x4*>(ib + ((ql * 2 + oa) * 2 + b) * 1024);
+            const int yy = ey0 + 4 * tg + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
+            const bool ok = yy < H && xx < W;
+            const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float z = fmaf(mine[ql][oa][b][e] + other[e], ms[e], bs[e]);
+              v[e] = fmaxf(z, slope * z);           // none / relu / leaky relu for slope 1 / 0 / 0.2 (a non-finite z trips chk)
+            }
+            if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb);
+            if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb);
+            if (ok && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+          }
       }
     }
-    const int cb = ent * 32 + 4 * half;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + (cb + 8 * q) * 4);
-      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + (cb + 8 * q) * 4);
-      f32x4 y[2][2];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * q + e;
-        float R[4][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          R[x][0] = acc[x * 4 + 0][r] + acc[x * 4 + 1][r] + acc[x * 4 + 2][r];
-          R[x][1] = acc[x * 4 + 1][r] - acc[x * 4 + 2][r] - acc[x * 4 + 3][r];
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          y[0][b][e] = R[0][b] + R[1][b] + R[2][b];
-          y[1][b][e] = R[1][b] - R[2][b] - R[3][b];
-        }
-      }
-#pragma unroll
-      for (int oa = 0; oa < 2; ++oa)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int yy = ey0 + 4 * wave + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
-          const bool ok = yy < H && xx < W;
-          const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act1(fmaf(y[oa][b][e], ms[e], bs[e]), slope, alo_);
-          if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb + 8 * q);
-          if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb + 8 * q);
-          if (ok && cb + 8 * q < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb + 8 * q) = v;
-        }
+    if (__any(chk != chk)) {
+      if (lane == 0) atomicOr(a.ovf, 1);
     }
+#if defined(WINO_PROF)
+    pw[3] += __builtin_readcyclecounter() - qe0;
+#endif
     u = un;
     if (u >= nunits) break;
   }
+#if defined(WINO_PROF)
+  if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
+    atomicAdd(a.dbg + 0, pw[0]); atomicAdd(a.dbg + 1, pw[1]); atomicAdd(a.dbg + 2, __builtin_readcyclecounter() - pw_t0);
+    atomicAdd(a.dbg + 3, pw[3]); atomicAdd(a.dbg + 4, 1ull); atomicAdd(a.dbg + 5, pw[5]); atomicAdd(a.dbg + 6, pw[6]);
+  }
+#endif
 #undef W2_SETUP_UNIT
 #undef W2_DMA
 #undef W2_A_SLOT
 #undef W2_ISSUE
+#undef W2_CHUNK_SCALARS
 }
 
 static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2) {
@@ -680,9 +789,9 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
     return hipGetLastError() == hipSuccess ? 0 : -2;
   };
   if (version == 2) {
-    if (res == 0) return go(conv_wino2_kernel<0>, 256);
-    if (res == 1) return go(conv_wino2_kernel<1>, 256);
-    return go(conv_wino2_kernel<2>, 256);
+    if (res == 0) return go(conv_wino2_kernel<0>, 512);
+    if (res == 1) return go(conv_wino2_kernel<1>, 512);
+    return go(conv_wino2_kernel<2>, 512);
   }
   if (res == 0) return go(conv_wino_kernel<0>, 512);
   if (res == 1) return go(conv_wino_kernel<1>, 512);

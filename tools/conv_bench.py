@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--batch", type=int, default=0, help="override the batch size of every shape (0: as listed)")
     ap.add_argument("--precision", default="exact", choices=["exact", "f16x3"])
     ap.add_argument("--ablate", type=int, default=0,
                     help="experiment switches (hcf_debug_set_ablation): 1 / 2 16-row tile for the 32 / 64-channel kernel, "
@@ -43,6 +44,8 @@ def main():
     for i, (name, B, H, W, srcs, cout, k) in enumerate(SHAPES):
         if args.only >= 0 and i != args.only:
             continue
+        if args.batch:
+            B = args.batch
         arr = (C.c_int32 * len(srcs))(*srcs)
         ms, fl = C.c_double(), C.c_double()
         rc = lib.hcf_bench_conv(B, H, W, arr, len(srcs), cout, k, args.iters, C.byref(ms), C.byref(fl), st)
