@@ -89,6 +89,7 @@ struct WgradArgs {
   int taps;                // 9 (3x3, pad 1) or 1
   float* dw;               // [cout][cin_total][taps], accumulated (caller zero-initialises)
   int negate;              // dW -= ... instead of += (the inverse 1x1 conv's weight gradient)
+  const float* g_max;      // nullable (device): max |g|; non-null selects the f16x3 matrix-core kernel (g scaled by a power of two)
   float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
   size_t part_cap;         // capacity of `part` in floats
   int cin_total, tpb;      // set by the launcher
@@ -96,6 +97,7 @@ struct WgradArgs {
 };
 size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);
+int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |g| (out zero-initialised)
 
 // ---- device-side weight repack (hcf_repack.hip) -------------------------------------------------------------------
 struct RepackArgs {

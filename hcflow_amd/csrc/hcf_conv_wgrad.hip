@@ -16,6 +16,7 @@
 //            (deterministic; the first version used fp32 atomics and spent 10-25x the MFMA time in them).
 #include "hcf_common.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace hcf {
 namespace wgrad {
@@ -171,6 +172,257 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       part[t * 1024 + (qi * 16 + 4 * kk + r) * 32 + qj * 16 + l16] = acc[t][r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the f16 matrix cores (f16x3 precision mode, training): both operands are dynamic, so both are
+// split into f16 hi / lo in the staging pass (X as is -- the taped forward pass already range-checked it in the same split;
+// G multiplied by a power of two that puts its max |g| (a.g_max, written by the epilogue backward) at 2^13..2^14, undone when
+// the partial tile is stored) and every product is x_hi g_hi + (x_lo 2^11)(g_hi 2^-11) + x_hi g_lo in
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate): per tap a [32 ic] x [32 oc] x [16 pixels] MFMA instead of four 16x16x4 fp32 ones, 16x the matrix rate.
+// K = pixels, but the tensors are channel-major (NHWC): the LDS images stay [pixel][32 channels] f16 (64 B per pixel, hi and
+// lo planes) and the fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16 -- a 16-lane group reads a
+// [4 pixels][16 channels] block (lane i: pixel i / 4, channels 4 (i % 4) .. + 3) and lane c receives the four pixels of
+// channel c, i.e. exactly four consecutive K values of an MFMA operand row; two reads give the eight a lane needs. A tap
+// only moves the pixel index, so all 9 taps read the same halo image at different (immediate) offsets, and 32 lanes of one
+// read cover 256 contiguous bytes (conflict-free).
+// Block = 8 waves (one image row of the 8 x 32 tile each, all 9 taps: 144 accumulator registers), one block per CU slot of
+// 76 KB LDS; the eight per-wave partial tiles are added in a fixed tree through LDS, then the same scratch / reduce path.
+typedef short v4i16 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v4i16* lds_v4i16;
+
+// eight consecutive K (pixel) values of this lane's channel: pixels +0..3 and +4..7 (4 x 64 B further)
+__device__ __forceinline__ f16x8 tr8(const char* p) {
+  const v4i16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16)(p));
+  const v4i16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16)(p + 256));
+  const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(f16x8, r);
+}
+// f16 hi / lo split of four fp32 values: hi = RNE pairs; lo = f16((v - hi) * 2^11) in one mixed-precision FMA per value
+// (fma(hi, -2^11, v * 2^11): hi read as f16, the rest fp32). The 2^11 keeps lo a NORMAL f16 whenever |v| >= 6e-5 -- with an
+// unscaled lo, activations below ~0.1 lose their low half to f16 denormals (3e-8 absolute) -- and is undone on the other
+// operand: the x_lo term multiplies by g_hi * 2^-11 (third G plane).
+__device__ __forceinline__ void split_hl_x(const f32x4 v, u32x2& h, u32x2& l) {
+  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
+  const uint32_t H0 = __builtin_bit_cast(uint32_t, h01), H1 = __builtin_bit_cast(uint32_t, h23);
+  const float k = -2048.f;
+  const f32x4 v2 = v * 2048.f;
+  uint32_t L0, L1;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(L0) : "v"(H0), "v"(k), "v"(v2.x));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L0) : "v"(H0), "v"(k), "v"(v2.y));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(L1) : "v"(H1), "v"(k), "v"(v2.z));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L1) : "v"(H1), "v"(k), "v"(v2.w));
+  h = u32x2{H0, H1};
+  l = u32x2{L0, L1};
+}
+// G (already scaled to max ~2^14): hi, lo = f16(v - hi), and hs = f16(hi * 2^-11) for the x_lo term
+__device__ __forceinline__ void split_hl_g(const f32x4 v, u32x2& h, u32x2& l, u32x2& hs) {
+  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
+  const uint32_t H0 = __builtin_bit_cast(uint32_t, h01), H1 = __builtin_bit_cast(uint32_t, h23);
+  const float k = 1.f / 2048.f;
+  uint32_t L0, L1, S0, S1;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L0) : "v"(H0), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L0) : "v"(H0), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L1) : "v"(H1), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L1) : "v"(H1), "v"(v.w));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(S0) : "v"(H0), "v"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(S0) : "v"(H0), "v"(k));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(S1) : "v"(H1), "v"(k));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(S1) : "v"(H1), "v"(k));
+  h = u32x2{H0, H1};
+  l = u32x2{L0, L1};
+  hs = u32x2{S0, S1};
+}
+
+template <int TAPS> struct Wg16 {
+  static constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  static constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
+  static constexpr int XB = HP * 64, GB = TH * TW * 64;          // bytes of one f16 plane of the X halo / the G tile
+  static constexpr int LDS_BYTES = 2 * XB + 3 * GB;              // 92 672 (3x3) / 81 920 (1x1): X hi, lo'; G hi, lo, hi * 2^-11
+};
+
+template <int TAPS, bool VEC>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArgs a) {
+  typedef Wg16<TAPS> C;
+  constexpr int PAD = C::PAD, HW = C::HW, HP = C::HP, XB = C::XB, GB = C::GB;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const xh = lds;
+  char* const gh = lds + 2 * XB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = a.B * tiles_x * tiles_y;
+
+  int blk = blockIdx.y, si = 0;
+  for (; si < a.nsrc; ++si) {
+    const int nb = (a.src[si].n + 31) >> 5;
+    if (blk < nb) break;
+    blk -= nb;
+  }
+  const View sv = a.src[si];
+  const int ic0 = blk * 32;
+  const int icn = min(32, sv.n - ic0);
+  const int oc0 = blockIdx.z * 32;
+  const int ocn = min(32, a.g.n - oc0);
+  const int up = sv.up, Hs = H >> up, Ws = W >> up;
+
+  float g_s = 1.f, g_inv = 1.f;                  // G * g_s has its max |g| in [2^13, 2^14)
+  {
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.g_max)));
+    if (mx > 0.f && mx < 3.0e38f) {
+      int ex = 0;
+      (void)frexpf(mx, &ex);
+      g_s = ldexpf(1.f, 14 - ex);
+      g_inv = ldexpf(1.f, ex - 14);
+    }
+  }
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // register staging of the next tile, branch-free (see conv_wgrad_kernel): clamped addresses, masks applied at the LDS write
+  constexpr int NX = (HP * 8 + 511) / 512, NG = (TH * TW * 8) / 512;
+  f32x4 rx[NX], rg[NG];
+  unsigned mskx = 0, mskg = 0;
+  const int c4t = (tid & 7) * 4;
+  const int vx = max(0, min(4, icn - c4t)), vg = max(0, min(4, ocn - c4t));
+  const int c4x = min(c4t, max(0, (icn - 1) & ~3)), c4g = min(c4t, max(0, (ocn - 1) & ~3));
+  const float* const xbase = sv.p + sv.c0 + ic0;
+  const float* const gbase = a.g.p + a.g.c0 + oc0;
+#define HCF_WG_LOAD(TILE)                                                                                     \
+  {                                                                                                           \
+    const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, b_ = (TILE) / (tiles_x * tiles_y); \
+    const int x0_ = txb_ * TW, y0_ = tyb_ * TH;                                                               \
+    mskx = 0;                                                                                                 \
+    _Pragma("unroll") for (int s_ = 0; s_ < NX; ++s_) {                                                       \
+      const int hp = min((tid + 512 * s_) >> 3, HP - 1);                                                      \
+      const int hy = hp / HW, hx = hp - hy * HW;                                                              \
+      const int y = y0_ + hy - PAD, x = x0_ + hx - PAD;                                                       \
+      mskx |= (y >= 0 && y < H && x >= 0 && x < W) ? (1u << s_) : 0u;                                         \
+      const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                           \
+      const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                            \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4x);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, icn - 1)]; v.y = p[min(c4t + 1, icn - 1)];                                           \
+        v.z = p[min(c4t + 2, icn - 1)]; v.w = p[min(c4t + 3, icn - 1)];                                       \
+      }                                                                                                       \
+      rx[s_] = v;                                                                                             \
+    }                                                                                                         \
+    mskg = 0;                                                                                                 \
+    _Pragma("unroll") for (int s_ = 0; s_ < NG; ++s_) {                                                       \
+      const int px = (tid + 512 * s_) >> 3;                                                                   \
+      const int y = y0_ + (px >> 5), x = x0_ + (px & 31);                                                     \
+      mskg |= (y < H && x < W) ? (1u << s_) : 0u;                                                             \
+      const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;       \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4g);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, ocn - 1)]; v.y = p[min(c4t + 1, ocn - 1)];                                           \
+        v.z = p[min(c4t + 2, ocn - 1)]; v.w = p[min(c4t + 3, ocn - 1)];                                       \
+      }                                                                                                       \
+      rg[s_] = v;                                                                                             \
+    }                                                                                                         \
+  }
+  // transpose-read lane offset: pixel (i / 4) + 8 (lane / 32), channels 16 ((lane / 16) & 1) + 4 (i % 4), i = lane % 16
+  const int lofs = (((lane & 15) >> 2) + 8 * (lane >> 5)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const char* const xw = xh + lofs + wave * (HW * 64);           // this wave's image row (row + dy through immediates)
+  const char* const gw = gh + lofs + wave * (TW * 64);
+
+  const int t0 = blockIdx.x * a.tpb, t1 = min(ntiles, t0 + a.tpb);
+  if (t0 < t1) HCF_WG_LOAD(t0)
+  for (int tile = t0; tile < t1; ++tile) {
+    __syncthreads();                              // the previous tile's fragments have been read
+#pragma unroll
+    for (int s_ = 0; s_ < NX; ++s_) {
+      const int q = tid + 512 * s_;
+      f32x4 v = rx[s_];
+      const bool ok = (mskx >> s_) & 1u;
+      v.x = (ok && vx > 0) ? v.x : 0.f; v.y = (ok && vx > 1) ? v.y : 0.f;
+      v.z = (ok && vx > 2) ? v.z : 0.f; v.w = (ok && vx > 3) ? v.w : 0.f;
+      u32x2 h, l;
+      split_hl_x(v, h, l);
+      if (q < HP * 8) {
+        *reinterpret_cast<u32x2*>(xh + (q >> 3) * 64 + c4t * 2) = h;
+        *reinterpret_cast<u32x2*>(xh + XB + (q >> 3) * 64 + c4t * 2) = l;
+      }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < NG; ++s_) {
+      const int q = tid + 512 * s_;
+      f32x4 v = rg[s_] * g_s;
+      const bool ok = (mskg >> s_) & 1u;
+      v.x = (ok && vg > 0) ? v.x : 0.f; v.y = (ok && vg > 1) ? v.y : 0.f;
+      v.z = (ok && vg > 2) ? v.z : 0.f; v.w = (ok && vg > 3) ? v.w : 0.f;
+      u32x2 h, l, hs;
+      split_hl_g(v, h, l, hs);
+      *reinterpret_cast<u32x2*>(gh + (q >> 3) * 64 + c4t * 2) = h;
+      *reinterpret_cast<u32x2*>(gh + GB + (q >> 3) * 64 + c4t * 2) = l;
+      *reinterpret_cast<u32x2*>(gh + 2 * GB + (q >> 3) * 64 + c4t * 2) = hs;
+    }
+    __syncthreads();
+    if (tile + 1 < t1) HCF_WG_LOAD(tile + 1)
+    // ---- K loop of this wave: its image row, two steps of 16 pixels, all taps
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+      const f16x8 bh = tr8(gw + hx * (16 * 64)), bl = tr8(gw + GB + hx * (16 * 64)), bs = tr8(gw + 2 * GB + hx * (16 * 64));
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
+        const int off = (dy * HW + 16 * hx + dx) * 64;
+        const f16x8 ah = tr8(xw + off), al = tr8(xw + XB + off);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bs, acc[t], 0, 0, 0);      // (x_lo 2^11) (g_hi 2^-11)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#undef HCF_WG_LOAD
+
+  // ---- fixed-order tree over the eight waves through LDS (two 36 KB slots): ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
+  float* const red = reinterpret_cast<float*>(lds);
+#define HCF_WG_ROUND(WR_LO, ADD_LO)      /* waves WR_LO, WR_LO + 1 publish; waves ADD_LO, ADD_LO + 1 accumulate */ \
+  __syncthreads();                                                                                            \
+  if (wave == (WR_LO) || wave == (WR_LO) + 1) {                                                               \
+    _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                          \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) red[(((wave - (WR_LO)) * TAPS + t) * 16 + r) * 64 + lane] = acc[t][r]; \
+  }                                                                                                           \
+  __syncthreads();                                                                                            \
+  if (wave == (ADD_LO) || wave == (ADD_LO) + 1) {                                                             \
+    _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                          \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[t][r] += red[(((wave - (ADD_LO)) * TAPS + t) * 16 + r) * 64 + lane]; \
+  }
+  HCF_WG_ROUND(6, 2)
+  HCF_WG_ROUND(4, 0)
+  HCF_WG_ROUND(2, 0)
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+#undef HCF_WG_ROUND
+  if (wave != 0) return;
+  float* part = a.part + ((size_t)((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (TAPS * 1024);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                // D[m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][n = lane & 31]
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      part[t * 1024 + m * 32 + (lane & 31)] = (acc[t][r] + red[(t * 16 + r) * 64 + lane]) * g_inv;
+    }
+}
+
 // dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nx, int taps) {
   const int icb = blockIdx.y, ocb = blockIdx.z;
@@ -200,7 +452,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
   a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += a.negate ? -s : s;
 }
 
+// max |g| over a channel window (float bits ordered like ints for non-negative values); *out zero-initialised by the caller
+__global__ __launch_bounds__(256) void absmax_kernel(View g, long long npix, float* out) {
+  float mx = 0.f;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256)
+    for (int c = 0; c < g.n; ++c) mx = fmaxf(mx, fabsf(g.p[(size_t)p * g.cs + g.c0 + c]));
+  __shared__ int shm;
+  if (threadIdx.x == 0) shm = 0;
+  __syncthreads();
+  if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
+  __syncthreads();
+  if (threadIdx.x == 0 && shm) atomicMax(reinterpret_cast<int*>(out), shm);
+}
+
 }  // namespace wgrad
+
+int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st) {
+  if (!g.p || !out) return HCF_ERR_ARG;
+  const long long npix = (long long)B * H * W;
+  const unsigned nb = (unsigned)std::min<long long>((npix + 255) / 256, 2048);
+  hipLaunchKernelGGL(wgrad::absmax_kernel, dim3(nb), dim3(256), 0, st, g, npix, out);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
 
 size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_tpb) {
   int nicb = 0;
@@ -208,7 +481,16 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   const int nocb = (a0.g.n + 31) >> 5;
   const int tiles = a0.B * ((a0.W + 31) / 32) * ((a0.H + 7) / 8);
   const int pairs = nicb * nocb;
-  int nblk_x = (512 + pairs - 1) / pairs;           // measured best of 512 / 768 / 1024 / 2048           // one resident round: 256 CUs x 2 blocks (phase-aligned rounds do not overlap)
+  // fp32 kernel: one resident round of 256 CUs x 2 blocks (measured best of 512 / 768 / 1024 / 2048; phase-aligned rounds do
+  // not overlap). The f16x3 kernel holds one 8-wave block per CU (92 KB of LDS).
+  static const int wg_blocks = getenv("HCF_WG_BLOCKS") ? atoi(getenv("HCF_WG_BLOCKS")) : 0;   // experiment knob, read once
+  int nblk_x;
+  if (a0.g_max) {                                   // at most one full round of 256 blocks (264 blocks would cost two)
+    const int target = wg_blocks > 0 ? wg_blocks : 256;
+    nblk_x = target / pairs;
+  } else {
+    nblk_x = ((wg_blocks > 0 ? wg_blocks : 512) + pairs - 1) / pairs;
+  }
   if (nblk_x > tiles) nblk_x = tiles;
   if (nblk_x < 1) nblk_x = 1;
   const int tpb = (tiles + nblk_x - 1) / nblk_x;
@@ -239,6 +521,24 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
   bool vec = (((a.g.cs | a.g.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.g.p) & 15) == 0);
   for (int i = 0; i < a.nsrc; ++i)
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
+  if (a.g_max) {
+    // f16 matrix cores (one-time opt-in to > 64 KB of dynamic LDS per instantiation)
+    static bool attr[4] = {false, false, false, false};
+    auto go = [&](auto fn, int idx, int ldsb) {
+      if (!attr[idx]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return false;
+        attr[idx] = true;
+      }
+      hipLaunchKernelGGL(fn, grid, dim3(512), ldsb, st, a);
+      return true;
+    };
+    bool ok;
+    if (a.taps == 9 && vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, true>, 0, wgrad::Wg16<9>::LDS_BYTES);
+    else if (a.taps == 9) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, false>, 1, wgrad::Wg16<9>::LDS_BYTES);
+    else if (vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<1, true>, 2, wgrad::Wg16<1>::LDS_BYTES);
+    else ok = go(wgrad::conv_wgrad_f16x3_kernel<1, false>, 3, wgrad::Wg16<1>::LDS_BYTES);
+    if (!ok) return HCF_ERR_HIP;
+  } else
   if (a.taps == 9 && vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, true>), grid, dim3(256), 0, st, a);
   else if (a.taps == 9) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, false>), grid, dim3(256), 0, st, a);
   else if (vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<1, true>), grid, dim3(256), 0, st, a);

@@ -247,6 +247,13 @@ int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const 
     wa.part_cap = conv_wgrad_scratch_floats(wa);
     wa.part = t.dev(wa.part_cap);
     if (!t.ok) return HCF_ERR_NOMEM;
+    if (rc == HCF_OK && g_op_precision == PREC_F16X3) {        // f16 matrix cores: g is scaled by a power of two from max |g|
+      float* gm = t.dev(1);
+      if (!t.ok) return HCF_ERR_NOMEM;
+      if (hipMemsetAsync(gm, 0, sizeof(float), st) != hipSuccess) return HCF_ERR_HIP;
+      rc = launch_absmax(gv, B, H, W, gm, st);
+      wa.g_max = gm;
+    }
     if (rc == HCF_OK) rc = launch_conv_wgrad(wa, st);
     if (rc == HCF_OK && hipMemcpyAsync(dw, wa.dw, nw * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) rc = HCF_ERR_HIP;
   }

@@ -53,6 +53,31 @@ def test_conv2d_backward(case, precision):
     assert _rel(db, b64.grad) <= 1e-6
 
 
+@pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e4])
+def test_conv2d_weight_gradient_f16x3_ranges(gscale):
+    """The f16 matrix-core weight gradient (hcf_conv_wgrad.hip, conv_wgrad_f16x3_kernel) scales G by a power of two taken
+    from max |g|: gradients of 1e-9 and of 3e4 keep fp32-class accuracy, and so do activations spanning six decades
+    (several tiles per block, ragged edges, two sources)."""
+    from hcflow_amd import ops
+    g = _gen(77)
+    B, H, W, cs, cout = 3, 40, 72, [64, 32], 32
+    srcs = [torch.randn(B, c, H, W, generator=g) * torch.logspace(-3, 3, c).view(1, c, 1, 1) for c in cs]
+    gy = torch.randn(B, cout, H, W, generator=g) * gscale
+    gy[:, :, : H // 2] *= 1e-3                                   # a quiet half: 1000x below the scaling reference
+    x = torch.cat(srcs, 1).double()
+    ref = torch.nn.grad.conv2d_weight(x, (cout, sum(cs), 3, 3), gy.double(), stride=1, padding=1)
+    ops.set_precision("f16x3")
+    try:
+        _, dw, _ = ops.conv2d_backward([s.cuda() for s in srcs], torch.zeros(cout, sum(cs), 3, 3), gy.cuda(), need_input_grads=False)
+        _, dw2, _ = ops.conv2d_backward([s.cuda() for s in srcs], torch.zeros(cout, sum(cs), 3, 3), gy.cuda(), need_input_grads=False)
+    finally:
+        ops.set_precision("exact")
+    assert torch.equal(dw, dw2)                                   # fixed reduction order
+    # per input channel (their magnitudes differ by 1e6): error relative to that channel's largest entry
+    err = (dw.double() - ref).abs().amax(dim=(0, 2, 3)) / ref.abs().amax(dim=(0, 2, 3))
+    assert float(err.max()) <= 5e-6, float(err.max())
+
+
 GRADS = ["grad_sr4_tiny", "grad_sr8_tiny"]
 
 
