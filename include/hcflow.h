@@ -243,8 +243,9 @@ int hcf_op_conv2d(const float* const* src, const int32_t* src_c, const int32_t* 
  * reference reaches it through loss.backward() in HCFlow_SR_model.optimize_parameters, HCFlow_SR_model.py:195-202):
  * g = dL/dy, device [B,cout,H,W]. dsrc[i] (device [B, src_c[i], H >> up, W >> up]) may be NULL; dw is a HOST buffer
  * [cout, cin, k, k], dbias a HOST buffer [cout]; either may be NULL. Data gradients run on the forward conv
- * kernels with transposed / flipped weights (process-wide op precision), the weight gradient on the fp32 MFMA
- * kernel of hcf_conv_wgrad.hip (accumulated with fp32 atomics). */
+ * kernels with transposed / flipped weights (process-wide op precision). The weight gradient runs on
+ * hcf_conv_wgrad.hip: fp32 MFMA in exact mode, the f16x3 matrix-core kernel (g scaled by a power of two from
+ * max |g|, both operands split) in f16x3 mode; split-K partial tiles are added in a fixed order (deterministic). */
 int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const int32_t* src_up, int32_t n_src,
                            int32_t B, int32_t H, int32_t W, const float* w, int32_t cout, int32_t k, const float* g,
                            float* const* dsrc, float* dw, float* dbias, hcf_stream_t stream);
