@@ -7,6 +7,7 @@
 // folded into the consumer's addressing and never materialised).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 
 #define HCF_OK 0
@@ -78,6 +79,11 @@ enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 // fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
+// Winograd F(2x2,3x3) form of the same f16x3 conv (hcf_conv_wino.hip): eligible layers only (pack size 0 otherwise);
+// HCF_ERR_UNSUPPORTED when the call cannot take it (upsampled source, unaligned views, > 2^24 pixels): use the direct kernel
+size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out);
+int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
+int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st);   // pack rebuilt from device weights
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------
 // dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)

@@ -67,6 +67,7 @@ struct Args {
 // w: PyTorch [cout][cin][3][3] (cin = sum of the source widths, each a multiple of 16). U = G g G^T in double, rows and
 // columns 2 negated, plane 0 = f16(U) * 2^11, plane 1 = f16((U - f16(U)) * 2^11).
 static inline bool pack_weights_wino(const float* w, int cin, int cout, std::vector<uint16_t>& pk) {
+#pragma clang fp contract(off)          /* bit-identical to the device-side rebuild (hcf_conv_wino.hip: repack_wino_kernel) */
   static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
   const int nchunk = cin / 16, ntn = (cout + 31) / 32;
   pk.assign(((size_t)ntn * nchunk + 1) * (W_BYTES / 2), 0);

@@ -1,0 +1,104 @@
+// Winograd F(2x2, 3x3) form of the f16x3 convolution (hcf_conv_wino.h) behind the engine's ConvArgs: used for plain 3x3
+// convs whose source windows are multiples of 16 channels, with >= 128 input channels and 32 / 64 output channels -- the
+// deep convs of the residual dense blocks (RRDBNet_arch.py:18-34), where it beats the direct kernel (profiles/r02_notes.md).
+#include "hcf_common.h"
+#include "hcf_conv_wino.h"
+
+namespace hcf {
+
+// w: PyTorch [cout][cin][3][3]; bytes of the pack (or 0 when the layer is not eligible / a weight leaves the f16 range)
+size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out) {
+  out.clear();
+  if (!w || cin < 128 || (cout != 32 && cout != 64) || nsrc < 1 || nsrc > 3) return 0;
+  int sum = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    if (srcs[i] < 16 || (srcs[i] & 15)) return 0;
+    sum += srcs[i];
+  }
+  if (sum != cin) return 0;
+  std::vector<uint16_t> pk;
+  if (!wino::pack_weights_wino(w, cin, cout, pk)) return 0;
+  out.resize((pk.size() * 2 + 3) / 4);
+  memcpy(out.data(), pk.data(), pk.size() * 2);
+  return pk.size() * 2;
+}
+
+// Device-side rebuild of a Winograd pack from the PyTorch-layout weight in device memory (after an optimiser step): the same
+// arithmetic as wino::pack_weights_wino, one thread per (output channel, input channel).
+__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, uint16_t* __restrict__ pk) {
+#pragma clang fp contract(off)
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cin * cout) return;
+  const int oc = idx / cin, ic = idx - oc * cin;
+  const float* g = w + (size_t)idx * 9;
+  const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  double t[4][3], U[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+  const int nchunk = cin / 16, nt = oc >> 5, n = oc & 31, c = ic >> 4, h = (ic >> 3) & 1, e = ic & 7;
+  for (int xi = 0; xi < 4; ++xi)
+    for (int nu = 0; nu < 4; ++nu) {
+      const double u = U[xi][nu] * ((xi == 2) ? -1.0 : 1.0) * ((nu == 2) ? -1.0 : 1.0);
+      const float x = (float)u;
+      const _Float16 hi = (_Float16)x;       // (|x| 2^11 beyond the f16 range becomes inf: the conv raises the range flag)
+      const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((float)((u - (double)(float)hi) * 2048.0));
+      const size_t o = ((size_t)(nt * nchunk + c) * wino::W_BYTES) / 2 + (size_t)(((xi * 4 + nu) * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
+      pk[o] = __builtin_bit_cast(uint16_t, p0);
+      pk[o + 512] = __builtin_bit_cast(uint16_t, p1);
+    }
+}
+
+int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st) {
+  if (!w_dev || !pk || cin < 16 || (cin & 15) || (cout & 31)) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, w_dev, cin, cout,
+                     reinterpret_cast<uint16_t*>(pk));
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) {
+  if (!wpack_wino || a.nsrc < 1 || a.nsrc > 3 || a.w2 || a.tC > 0 || a.in_max) return HCF_ERR_UNSUPPORTED;
+  wino::Args w;
+  memset(&w, 0, sizeof(w));
+  int cin = 0;
+  for (int i = 0; i < a.nsrc; ++i) {
+    if (a.src[i].up != 0) return HCF_ERR_UNSUPPORTED;
+    w.src[i] = wino::Src{a.src[i].p, a.src[i].cs, a.src[i].c0, a.src[i].n};
+    cin += a.src[i].n;
+  }
+  for (int i = a.nsrc; i < 3; ++i) w.src[i] = w.src[0];
+  w.nsrc = a.nsrc;
+  w.B = a.B; w.H = a.H; w.W = a.W;
+  w.wpack = reinterpret_cast<const char*>(wpack_wino);
+  w.nchunk = cin / 16;
+  w.ntile_n = a.out.n / 32;
+  if (w.ntile_n * 32 != a.out.n) return HCF_ERR_UNSUPPORTED;
+  w.bias = a.bias; w.scale = a.scale; w.act = a.act;
+  w.out = a.out.p; w.out_cs = a.out.cs; w.out_c0 = a.out.c0; w.cout = a.out.n;
+  if (a.res1.p) { w.res1 = a.res1.p; w.res1_cs = a.res1.cs; w.res1_c0 = a.res1.c0; w.rs1 = a.rs1; }
+  if (a.res2.p) {
+    if (!a.res1.p) return HCF_ERR_UNSUPPORTED;
+    w.res2 = a.res2.p; w.res2_cs = a.res2.cs; w.res2_c0 = a.res2.c0; w.rs2 = a.rs2;
+  }
+  w.ovf = a.ovf;
+  w.zeros = reinterpret_cast<const char*>(a.zeros);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    ncu = v;
+  }
+  // One persistent block per CU walks units of 16 x 32 pixels x 32 channels: a grid of a few rounds with a ragged last one
+  // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of
+  // config 2, 800 / 1600 units on 256 CUs = 78 / 89 %, measured equal / slightly better here, stays.)
+  {
+    const long long nunits = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 15) / 16) * w.ntile_n;
+    const long long rounds = (nunits + ncu - 1) / ncu;
+    if (rounds >= 2 && nunits * 100 < rounds * ncu * 75) return HCF_ERR_UNSUPPORTED;
+  }
+  const int r = wino::launch(w, ncu, st, 2);
+  return r == 0 ? HCF_OK : r == -6 ? HCF_ERR_UNSUPPORTED : r == -2 ? HCF_ERR_HIP : HCF_ERR_ARG;
+}
+
+}  // namespace hcf

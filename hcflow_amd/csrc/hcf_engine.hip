@@ -39,10 +39,13 @@ struct Spec {
 };
 
 // One fused conv layer, packed for conv_mfma_kernel
+extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip (hcf_debug_set_ablation; bit 256: no Winograd kernels)
+
 struct Conv {
   int taps = 9, cout = 0, nsrc = 0, src_n[kMaxSrc] = {0, 0, 0}, nchunk = 0, npad = 0, act = ACT_NONE;
   float *wpack = nullptr, *bias = nullptr, *scale = nullptr;   // device
   float* wpack16 = nullptr;                                     // device, f16x3 split pack (or null: exact only)
+  float* wpack_wino = nullptr;                                  // device, Winograd f16x3 pack (eligible dense-block convs only)
   double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
   std::string an_key;                                           // Basic.Conv2d: prefix of its ActNorm ("....conv1.actnorm")
   // training path: state_dict keys of the parameters behind this layer and what the epilogue sums mean for them
@@ -191,6 +194,10 @@ struct hcf_engine {
   int* ovf_flag = nullptr;     // device: [0] = range flag, bytes 64..191 = zero page for the f16x3 kernel
   int64_t n_fallbacks = 0;
   bool taping = false;         // a training forward is being recorded: no fused epilogues
+  // Winograd packs of the eligible convs (built by hcf_finalize, rebuilt on the device by hcf_refresh_from_device);
+  // HCF_NO_WINO=1 keeps them from being built at all.
+  bool wino_enabled = getenv("HCF_NO_WINO") == nullptr;
+  bool wino_stale = false;
   // ActNorm data-dependent initialisation (ActNorms.py:29-43), armed for ONE forward pass by hcf_actnorm_init_request
   std::set<std::string> an_pending, an_fitted;
   bool an_active = false;
@@ -287,6 +294,11 @@ struct hcf_engine {
       std::vector<float> pk16;
       int nc = 0, np = 0;
       if (pack_conv_weights_f16x3(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk16, nc, np)) cv.wpack16 = upload(pk16);
+    }
+    cv.wpack_wino = nullptr;
+    if (cv.wpack16 && cv.taps == 9 && wino_enabled) {
+      std::vector<float> pkw;
+      if (pack_conv_weights_wino(w, cin, cout, srcs.data(), cv.nsrc, pkw)) cv.wpack_wino = upload(pkw);
     }
   }
 
@@ -601,8 +613,15 @@ struct hcf_engine {
       }
       hipEventRecord(prof_events[prof_used].e0, st);
     }
-    int r;
-    if (use_f16 && cv.wpack16 && cv.taps == 9) {
+    int r = HCF_ERR_UNSUPPORTED;
+    if (use_f16 && cv.wpack_wino && !fuse2 && !tail && !taping && !wino_stale && !(g_f16x3_ablation & 256)) {
+      a.ovf = ovf_flag;
+      a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
+      r = launch_conv_wino(a, cv.wpack_wino, st);      // HCF_ERR_UNSUPPORTED: this call's views do not qualify
+      if (r == HCF_OK && prof) prof_events[prof_used].kind = 4;
+    }
+    if (r != HCF_ERR_UNSUPPORTED) {
+    } else if (use_f16 && cv.wpack16 && cv.taps == 9) {
       a.wpack = cv.wpack16;
       a.ovf = ovf_flag;
       a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
@@ -1246,6 +1265,7 @@ int hcf_finalize(hcf_engine* e, int device) {
   e->cc_valid = false;
   e->invalidate_tapes();
   e->host_stale = false;
+  e->wino_stale = false;       // build() re-packs the Winograd form from the host weights
   e->device = device;
   e->spec_mode = false;
   e->rc = HCF_OK;

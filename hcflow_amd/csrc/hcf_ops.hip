@@ -56,8 +56,18 @@ static int pack_and_launch(Tmp& t, ConvArgs& a, const float* w, int cin, int cou
   a.wpack = t.up(pk);
   a.nchunk = nchunk;
   if (!t.ok) return HCF_ERR_NOMEM;
+  const float* wino = nullptr;             // eligible layers take the Winograd form, as in the engine (--ablate 256: off)
+  if (f16 && !(g_f16x3_ablation & 256)) {
+    std::vector<float> pkw;
+    if (pack_conv_weights_wino(w, cin, cout, srcs, n_src, pkw)) wino = t.up(pkw);
+    if (!t.ok) return HCF_ERR_NOMEM;
+  }
   int rc = HCF_OK;
-  for (int i = 0; i < iters && rc == HCF_OK; ++i) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
+  for (int i = 0; i < iters && rc == HCF_OK; ++i) {
+    rc = HCF_ERR_UNSUPPORTED;
+    if (wino) rc = launch_conv_wino(a, wino, st);
+    if (rc == HCF_ERR_UNSUPPORTED) rc = f16 ? launch_conv_f16x3(a, k * k, st) : launch_conv(a, k * k, st);
+  }
   return rc;
 }
 

@@ -1,0 +1,115 @@
+"""-m gpu: the Winograd F(2x2, 3x3) form of the f16x3 convolution (hcf_conv_wino.h / hcf_conv_wino.hip), which the engine
+and the op entry use for plain 3x3 convs with >= 128 input channels in 16-channel-aligned source windows and 32 / 64 output
+channels (the deep convs of the residual dense blocks, RRDBNet_arch.py:18-34): fp32-class accuracy against an fp64
+evaluation, agreement with the direct f16x3 kernel, range reporting, and that the engine really takes it."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_ops import _rel, _gen
+
+pytestmark = pytest.mark.gpu
+
+# B, H, W, source channels, cout, act, residuals
+WINO_CASES = [
+    (2, 16, 32, [64, 64], 32, "lrelu", 0),          # RDB conv3, exact unit grid
+    (1, 24, 40, [64, 96], 32, "lrelu", 0),          # RDB conv4, ragged unit edges (24 = 16 + 8 rows, 40 = 32 + 8 columns)
+    (2, 19, 37, [64, 128], 64, None, 1),            # RDB conv5 with the dense-block residual, odd sizes
+    (1, 33, 70, [64, 128], 64, None, 2),            # ... and with the RRDB skip as second residual
+    (1, 8, 8, [128], 32, "relu", 0),                # a single unit, one source
+    (3, 48, 64, [160], 32, "lrelu", 0),             # several units per block
+]
+
+
+def _ablate(bits):
+    from hcflow_amd import _lib
+    assert _lib.load().hcf_debug_set_ablation(bits) == 0
+
+
+@pytest.fixture()
+def f16x3_ops():
+    from hcflow_amd import ops
+    ops.set_precision("f16x3")
+    yield ops
+    ops.set_precision("exact")
+    _ablate(0)
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_matches_fp64_and_direct(f16x3_ops, case):
+    ops = f16x3_ops
+    B, H, W, cs, cout, act, nres = case
+    g = _gen(sum(cs) + H + W)
+    srcs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    cin = sum(cs)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    scale = torch.exp(torch.randn(cout, generator=g) * 0.1)
+    res = [torch.randn(B, cout, H, W, generator=g) for _ in range(nres)]
+    ref = (F.conv2d(torch.cat(srcs, 1).double(), w.double(), None, 1, 1) + bias.view(1, -1, 1, 1)) * scale.view(1, -1, 1, 1)
+    ref = F.relu(ref) if act == "relu" else F.leaky_relu(ref, 0.2) if act == "lrelu" else ref
+    kw = {}
+    if nres >= 1:
+        ref = ref * 0.2 + res[0].double()
+        kw.update(res1=res[0].cuda(), rs1=0.2)
+    if nres == 2:
+        ref = ref * 0.2 + res[1].double()
+        kw.update(res2=res[1].cuda(), rs2=0.2)
+    dev = [s.cuda() for s in srcs]
+    _ablate(0)
+    out = ops.conv2d(dev, w, bias, scale, act, **kw)
+    out2 = ops.conv2d(dev, w, bias, scale, act, **kw)
+    _ablate(256)                                           # the direct f16x3 kernel on the same call
+    direct = ops.conv2d(dev, w, bias, scale, act, **kw)
+    _ablate(0)
+    assert torch.equal(out, out2)
+    assert _rel(out, ref.float()) <= 3e-6, (case, _rel(out, ref.float()))
+    assert _rel(direct, ref.float()) <= 3e-6
+    assert not torch.equal(out, direct)                    # (different summation: proves the other kernel ran)
+    assert _rel(out, direct) <= 4e-6
+
+
+def test_winograd_out_of_range_is_reported(f16x3_ops):
+    from hcflow_amd import _lib
+    x = torch.ones(1, 128, 16, 32)
+    x[0, 77, 9, 21] = 1.0e5                    # beyond the f16 range: the transformed value overflows the hi part
+    w = torch.randn(32, 128, 3, 3, generator=_gen(1)) * 0.05
+    with pytest.raises(_lib.HcfError):
+        f16x3_ops.conv2d([x.cuda()], w)
+
+
+def test_engine_uses_winograd_for_the_deep_dense_block_convs():
+    """SR x4 tiny net, f16x3 inverse pass: conv3 / conv4 / conv5 of every RDB run as kind 4 (the others as before), the result
+    stays within the f16x3 tolerance of the exact kernels and is bit-reproducible; --ablate 256 gives the direct kernels."""
+    from hcflow_amd.config import preset, eps_shapes
+    from tests.util import cached_params, maxdiff
+    from tests.test_gpu_nets import build_net
+    cfg = preset("SR_4X_tiny")
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    g = torch.Generator().manual_seed(5)
+    B, size = 2, 40
+    lr = torch.rand(B, 3, size, size, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, size, size)]
+    with torch.no_grad():
+        ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+        net.set_precision("f16x3")
+        try:
+            a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            eng = net.engine()
+            eng.profile_convs(True)
+            b = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            ms1, n1, _, _ = eng.conv_time(9, 1, kind=4)
+            ms2, n2, _, _ = eng.conv_time(9, 2, kind=4, reset=True)
+            _ablate(256)
+            d = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            _, n3, _, _ = eng.conv_time(9, 0, kind=4, reset=True)
+            eng.profile_convs(False)
+        finally:
+            _ablate(0)
+            net.set_precision("exact")
+    assert n1 > 0 and n2 > 0 and n3 == 0, (n1, n2, n3)
+    assert torch.equal(a, b)
+    tol = 2e-5 * max(1.0, float(ex.abs().max()))
+    assert maxdiff(a, ex) <= tol and maxdiff(d, ex) <= tol
