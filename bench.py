@@ -43,18 +43,19 @@ PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec
 GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
 # (label, taps, n-tiles, kind) of the conv instantiations a pass launches; kind: see include/hcflow.h hcf_conv_time_ms
+# + the keys of that instantiation in profiles/rNN_traffic_pmc.json (tools/pmc_traffic.py)
 VARIANTS = {
-    "f16x3": [("hcf::f16x3::conv_f16x3_kernel<2,true,false,false,0,8,false> plain 3x3, 33..64 out-ch", 9, 2, 0),
-              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,0,8,false> plain 3x3, <=32 out-ch", 9, 1, 0),
-              ("hcf::wino::conv_wino2_kernel<*> Winograd F(2x2,3x3) form, 64 out-ch, >= 128 in-ch (RDB conv5)", 9, 2, 4),
-              ("hcf::wino::conv_wino2_kernel<0> Winograd F(2x2,3x3) form, 32 out-ch, >= 128 in-ch (RDB conv3 / conv4)", 9, 1, 4),
-              ("hcf::f16x3::conv_f16x3_kernel<2,true,*,true,0,8,false> FCN conv1 3x3 + conv2 1x1 (FUSE2)", 9, 2, 1),
-              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2),
-              ("hcf::f16x3::conv_f16x3_kernel<2,true,true,false,0,8,false> conv_first on upsampled LR (UP)", 9, 2, 3),
-              ("hcf::conv_mfma_kernel<1,*,true> 1x1 convs left on the exact fp32 kernel", 1, 0, -1)],
-    "exact": [("hcf::conv_mfma_kernel<9,2,true> 3x3, 33..64 out-ch", 9, 2, -1),
-              ("hcf::conv_mfma_kernel<9,1,true> 3x3, <=32 out-ch", 9, 1, -1),
-              ("hcf::conv_mfma_kernel<1,2,true> 1x1", 1, 2, -1), ("hcf::conv_mfma_kernel<1,1,true> 1x1", 1, 1, -1)],
+    "f16x3": [("hcf::f16x3::conv_f16x3_kernel<2,true,false,false,0,8,false> plain 3x3, 33..64 out-ch", 9, 2, 0, ["f16x3<2>"]),
+              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,0,8,false> plain 3x3, <=32 out-ch", 9, 1, 0, ["f16x3<1>"]),
+              ("hcf::wino::conv_wino2_kernel<1|2> Winograd F(2x2,3x3) form, 64 out-ch, >= 128 in-ch (RDB conv5)", 9, 2, 4, ["wino<1>", "wino<2>"]),
+              ("hcf::wino::conv_wino2_kernel<0> Winograd F(2x2,3x3) form, 32 out-ch, >= 128 in-ch (RDB conv3 / conv4)", 9, 1, 4, ["wino<0>"]),
+              ("hcf::f16x3::conv_f16x3_kernel<2,true,*,true,0,8,false> FCN conv1 3x3 + conv2 1x1 (FUSE2)", 9, 2, 1, ["f16x3<2>+fuse2"]),
+              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2, []),
+              ("hcf::f16x3::conv_f16x3_kernel<2,true,true,false,0,8,false> conv_first on upsampled LR (UP)", 9, 2, 3, ["f16x3<2>+up"]),
+              ("hcf::conv_mfma_kernel<1,*,true> 1x1 convs left on the exact fp32 kernel", 1, 0, -1, [])],
+    "exact": [("hcf::conv_mfma_kernel<9,2,true> 3x3, 33..64 out-ch", 9, 2, -1, ["exact<9,2>"]),
+              ("hcf::conv_mfma_kernel<9,1,true> 3x3, <=32 out-ch", 9, 1, -1, ["exact<9,1>"]),
+              ("hcf::conv_mfma_kernel<1,2,true> 1x1", 1, 2, -1, ["exact<1,2>"]), ("hcf::conv_mfma_kernel<1,1,true> 1x1", 1, 1, -1, ["exact<1,1>"])],
 }
 IDEAL_GB_PER_IMAGE = 23.02            # layer-wise-ideal fp32 HBM traffic per image
 
@@ -158,10 +159,10 @@ def main():
 
     def roofline_block(eng, mode, steps, dt):
         variants = []
-        for label, taps_, nt_, kind_ in VARIANTS[mode]:
+        for label, taps_, nt_, kind_, tkeys_ in VARIANTS[mode]:
             vms, vn, vfl, vby = eng.conv_time(taps_, nt_, kind=kind_)
             if vn:
-                variants.append({"kernel": label, "launches_per_step": vn // steps, "ms_per_step": round(vms / steps, 3),
+                variants.append({"kernel": label, "_tkeys": tkeys_, "launches_per_step": vn // steps, "ms_per_step": round(vms / steps, 3),
                                  "avg_launch_us": round(1e3 * vms / vn, 2), "gflop_per_launch": round(vfl / vn / 1e9, 3),
                                  "tflops": round((vfl / 1e12) / (vms / 1e3), 2),
                                  "algorithmic_GB_per_launch": round(vby / vn / 1e9, 4),
@@ -175,13 +176,17 @@ def main():
             peak = PEAK_F16_MFMA_TFLOPS / 3
             pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts ALGORITHMIC "
                      "flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that")
+        if "wino" in dom["kernel"]:
+            pnote += ("; this kernel is the Winograd F(2x2,3x3) form: it executes 3 / 2.25 = 1.33x the algorithmic flops on the "
+                      "matrix cores (VALU-issue bound), the nominal 833 stays the yardstick for comparability with the direct form")
         traffic, tnote = None, ("not measured in this run (PMC counters need separate rocprofv3 --pmc passes: "
                                 "profiles/ holds them per round)")
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")))
-            ent = tj["kernels"].get(dom["kernel"].split(" ")[0])
-            if ent and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
-                traffic = round(ent["hbm_bytes_per_launch"] / 1e9, 4)
+            ents = [tj["kernels"][k] for k in dom["_tkeys"] if k in tj["kernels"]]
+            if ents and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:       # launch-weighted mean over the instantiation's keys
+                traffic = round(sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) /
+                                sum(e["launches_sampled"] for e in ents) / 1e9, 4)
                 tnote = "GB per launch, REPLAYED from profiles/r02_traffic_pmc.json (" + tj["source"] + "), not measured in this run"
         except (OSError, KeyError, ValueError):
             pass
@@ -191,7 +196,7 @@ def main():
             "algorithmic_GB_per_launch": dom["algorithmic_GB_per_launch"], "launches": dom["launches_per_step"] * steps,
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "selection": "instantiation with the largest total time in the timed region",
-            "conv_kernels": variants,
+            "conv_kernels": [{k: v for k, v in x.items() if k != "_tkeys"} for x in variants],
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / steps, 3),
                           "tflops": round((fl_all / 1e12) / (ms_all / 1e3), 3) if ms_all > 0 else 0.0,
                           "frac_of_step_time": round(ms_all / 1e3 / dt, 4)}}

@@ -17,7 +17,7 @@ def main(d):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "conv_f16x3" not in k and "conv_mfma" not in k and "conv_wgrad" not in k:
+            if "conv_f16x3" not in k and "conv_mfma" not in k and "conv_wgrad" not in k and "conv_wino" not in k:
                 continue
             k = k.split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])

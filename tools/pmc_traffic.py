@@ -31,6 +31,9 @@ def short_name(k):
         if up == "true":
             tag += "+up"
         return tag
+    m = re.search(r"conv_wino2_kernel<(\d)>", k)
+    if m:
+        return "wino<%s>" % m.group(1)          # template argument = number of residual inputs (0: conv3 / conv4, 1 / 2: conv5)
     m = re.search(r"conv_mfma_kernel<(\d), (\d), (true|false)>", k)
     if m:
         return "exact<%s,%s>" % (m.group(1), m.group(2))
