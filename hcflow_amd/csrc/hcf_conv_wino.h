@@ -95,6 +95,39 @@ static inline bool pack_weights_wino(const float* w, int cin, int cout, std::vec
   return true;
 }
 
+// 64-output-channel layout of the v4 kernel: per 16-channel chunk 64 pieces of 1 KB, piece ((pos * 2 + ntile) * 2 + plane) =
+// [k-half 2][32 oc][8 halves]; same arithmetic as pack_weights_wino.
+constexpr int W4_BYTES = 65536;
+static inline bool pack_weights_wino64(const float* w, int cin, int cout, std::vector<uint16_t>& pk) {
+#pragma clang fp contract(off)
+  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  if (cout != 64 || (cin & 15)) return false;
+  const int nchunk = cin / 16;
+  pk.assign(((size_t)nchunk + 1) * (W4_BYTES / 2), 0);
+  for (int oc = 0; oc < cout; ++oc)
+    for (int ic = 0; ic < cin; ++ic) {
+      const float* g = w + ((size_t)oc * cin + ic) * 9;
+      double t[4][3], U[4][4];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) U[i][j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+      const int nt = oc >> 5, n = oc & 31, c = ic >> 4, h = (ic >> 3) & 1, e = ic & 7;
+      for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu) {
+          const double u = U[xi][nu] * ((xi == 2) ? -1.0 : 1.0) * ((nu == 2) ? -1.0 : 1.0);
+          const float x = (float)u;
+          if (!(fabsf(x) * 2048.f < 60000.f)) return false;
+          const _Float16 hi = (_Float16)x;
+          const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((float)((u - (double)(float)hi) * 2048.0));
+          const size_t o = (size_t)c * (W4_BYTES / 2) + (size_t)(((xi * 4 + nu) * 2 + nt) * 2) * 512 + (size_t)h * 256 + (size_t)n * 8 + e;
+          memcpy(&pk[o], &p0, 2);
+          memcpy(&pk[o + 512], &p1, 2);
+        }
+    }
+  return true;
+}
+
 #if defined(__HIPCC__)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -758,6 +791,333 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
 #undef W2_CHUNK_SCALARS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v4: the 64-output-channel form (RDB conv5). What bounds v3 is VALU issue (28 VALU per 3 MFMAs: every V value feeds one
+// 32-channel tile); here a wave owns ONE transform row of a tile group and BOTH channel tiles, so each V feeds 6 MFMAs
+// (152 VALU per 24 MFMAs per wave and chunk instead of 270). Unit = 8 x 32 pixels x 64 channels, 8 waves = 4 transform
+// rows x 2 tile groups, 8 accumulators (4 positions x 2 channel tiles) per wave.
+// LDS: the weights of a chunk are 64 KB (16 positions x 2 planes x 2 tiles x 1 KB), so W is double-buffered (128 KB) and the
+// 22 KB halo image is SINGLE-buffered: every wave reads its two patch rows right after the chunk barrier, a second barrier
+// ("rows are in registers") releases the image, and the next chunk's image DMA then has almost a whole chunk to land.
+namespace v4 {
+constexpr int TH4 = 8, HH4 = TH4 + 2;
+constexpr int A4_BYTES = 22 * 1024;               // 1 360 real pieces (10 x 34 pixels x 4 parts) + 48 dead
+constexpr int W4_OFF = A4_BYTES;                  // two weight buffers of W4_BYTES
+constexpr int TAB4_OFF = A4_BYTES + 2 * W4_BYTES; // 153 600
+constexpr int LDS4_BYTES = TAB4_OFF + 512;        // 154 112
+constexpr int NPIECE4 = 22 + 64;                  // DMA instructions per chunk
+}  // namespace v4
+
+template <int RES>
+__global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const int nunits) {
+  using namespace v4;
+  using v2::ROWB;
+  using v2::a2_off;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, li = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xi = wave & 3, tg = wave >> 2;       // transform row xi of tile group tg (output rows 4 tg .. 4 tg + 3)
+  const int H = a.H, W = a.W, nchunk = a.nchunk;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH4 - 1) / TH4;
+
+  // DMA instruction I = 8 j + wave, j = 0..10: I < 22 halo pieces, 22 <= I < 86 weight piece I - 22, I >= 86 nothing.
+  // j = 0, 1: halo; j = 2: halo for waves 0..5, weight pieces 0 / 1 for waves 6 / 7; j = 3..9: weights; j = 10: waves 0..5.
+  const bool whi = (wave >= 6);
+  const int padpix = a.B * H * W;                // out-of-range pixel index: the DMA writes zeros (conv padding / dead pieces)
+  int upix[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) upix[j] = padpix;
+  uint32_t partpk = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int pa_ = (8 * j + wave) * 64 + lane, hy_ = (pa_ * 241) >> 15, q_ = pa_ - hy_ * 136, m_ = q_ >> 4;
+    partpk |= (uint32_t)(((q_ & 15) ^ (m_ & 7)) & 3) << (4 + 2 * j);
+  }
+  const int k0 = __builtin_amdgcn_readfirstlane(a.src[0].n >> 4);
+  const int k1 = k0 + __builtin_amdgcn_readfirstlane(a.nsrc > 1 ? (a.src[1].n >> 4) : 0);
+  const long long npx = (long long)a.B * H * W;
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[0].p, 0, (int)(npx * a.src[0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[a.nsrc > 1 ? 1 : 0].p, 0, (int)(npx * a.src[a.nsrc > 1 ? 1 : 0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[a.nsrc > 2 ? 2 : 0].p, 0, (int)(npx * a.src[a.nsrc > 2 ? 2 : 0].cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, (nchunk + 1) * W4_BYTES, 0x00020000);
+  const int csb0 = __builtin_amdgcn_readfirstlane(a.src[0].cs) * 4, csb1 = __builtin_amdgcn_readfirstlane(a.src[1].cs) * 4,
+            csb2 = __builtin_amdgcn_readfirstlane(a.src[2].cs) * 4;
+  const int cb0 = __builtin_amdgcn_readfirstlane(a.src[0].c0) * 4, cb1 = __builtin_amdgcn_readfirstlane(a.src[1].c0) * 4,
+            cb2 = __builtin_amdgcn_readfirstlane(a.src[2].c0) * 4;
+  const int wvo = lane * 16;
+
+  int ub = 0, uy0 = 0, ux0 = 0, uc = 0;          // DMA cursor
+#define W4_SETUP_UNIT(U)                                                                           \
+  {                                                                                                \
+    const int v_ = xcd_remap((U), nunits);                                                         \
+    ux0 = __builtin_amdgcn_readfirstlane((v_ % tiles_x) * TW);                                     \
+    uy0 = __builtin_amdgcn_readfirstlane(((v_ / tiles_x) % tiles_y) * TH4);                        \
+    ub = __builtin_amdgcn_readfirstlane(v_ / (tiles_x * tiles_y));                                 \
+    uc = 0;                                                                                        \
+    int ln_ = lane;                                                                                \
+    asm volatile("" : "+v"(ln_));                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                \
+      const int pa_ = (8 * j + wave) * 64 + ln_;                                                   \
+      const int hy_ = (pa_ * 241) >> 15;                                                           \
+      const int q_ = pa_ - hy_ * 136, m_ = q_ >> 4;                                                \
+      const int hx_ = m_ * 4 + (((q_ & 15) ^ (m_ & 7)) >> 2);                                      \
+      const int y = uy0 + hy_ - 1, x = ux0 + hx_ - 1;                                              \
+      upix[j] = (hy_ < HH4 && y >= 0 && y < H && x >= 0 && x < W) ? (ub * H + y) * W + x : padpix; \
+    }                                                                                              \
+  }
+#define W4_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
+  int csb_ = 0, so_ = 0, ws_ = 0;
+  uint32_t pp_ = partpk;
+  __amdgpu_buffer_rsrc_t rsa_ = rs0;
+#define W4_CHUNK_SCALARS()                                                                         \
+  {                                                                                                \
+    const int sidx_ = (uc < k0) ? 0 : (uc < k1) ? 1 : 2;                                           \
+    csb_ = sidx_ == 0 ? csb0 : sidx_ == 1 ? csb1 : csb2;                                           \
+    rsa_ = sidx_ == 0 ? rs0 : sidx_ == 1 ? rs1 : rs2;                                              \
+    so_ = (sidx_ == 0 ? cb0 + uc * 64 : sidx_ == 1 ? cb1 + (uc - k0) * 64 : cb2 + (uc - k1) * 64); \
+    ws_ = uc * W4_BYTES;                                                                           \
+    pp_ = partpk;                                                                                  \
+    asm volatile("" : "+v"(pp_));                                                                  \
+  }
+#define W4_A_SLOT(J)                                                                               \
+  {                                                                                                \
+    const int p16_ = (int)((pp_ >> (2 * (J))) & 0x30u);                                            \
+    const int vo_ = (int)__umul24((unsigned)upix[J], (unsigned)csb_) + p16_;                       \
+    W4_DMA(rsa_, vo_, so_, lds + (8 * (J) + wave) * 1024);                                         \
+  }
+  // halo pieces of the cursor's chunk (the image is single-buffered: only after the "rows are in registers" barrier)
+#define W4_ISSUE_A()                                                                               \
+  {                                                                                                \
+    W4_A_SLOT(0) W4_A_SLOT(1)                                                                      \
+    if (!whi) W4_A_SLOT(2)                                                                         \
+  }
+  // weight pieces [J0, J1) (j index) of the cursor's chunk into weight buffer WB
+#define W4_ISSUE_W(J0, J1, WB)                                                                     \
+  {                                                                                                \
+    char* const wb_ = lds + W4_OFF + (WB) * W4_BYTES;                                              \
+    _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) {                                       \
+      const int q_ = 8 * j_ + wave - 22;                                                           \
+      if (j_ == 2) { if (whi) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024); }                \
+      else if (j_ < 10) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024);                        \
+      else if (!whi) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024);                           \
+    }                                                                                              \
+  }
+
+  // patch reads: transform row xi uses patch rows (rA, rB) = (0,2) (1,2) (1,2) (1,3): t = rA + sg rB, sg = -1, +1, -1, -1
+  const int trow = li >> 4, tcol = li & 15;
+  const int rA = (xi == 0) ? 0 : 1, rB = (xi == 3) ? 3 : 2;
+  const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (xi == 1) ? 1.f : -1.f)));
+  int poff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) poff[j] = a2_off(4 * tg + 2 * trow, 2 * tcol + j, 2 * half);
+  const int offA = rA * ROWB, offB = rB * ROWB;
+  const int fw = half * 512 + li * 16 + xi * (4 * 4 * 1024);      // + ((nu * 2 + ntile) * 2 + plane) * 1024
+
+  if (tid < 64) {
+    reinterpret_cast<float*>(lds + TAB4_OFF)[tid] = a.bias[tid] * a.scale[tid];
+    reinterpret_cast<float*>(lds + TAB4_OFF)[64 + tid] = a.scale[tid] * UNSPLIT;
+  }
+  int u = blockIdx.x;
+  if (u >= nunits) return;
+#if defined(WINO_PROF)
+  unsigned long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pw_t0 = __builtin_readcyclecounter();
+#endif
+  W4_SETUP_UNIT(u)
+  W4_CHUNK_SCALARS()
+  W4_ISSUE_A()
+  W4_ISSUE_W(2, 11, 0)
+  ++uc;
+  int g = 0;
+  const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+
+  while (true) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.f;
+    const int eb = ub, ey0 = uy0, ex0 = ux0;
+    const int un = u + gridDim.x;
+
+    for (int c = 0; c < nchunk; ++c, ++g) {
+      const int stg = g & 1;
+#if defined(WINO_PROF)
+      const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(WINO_PROF)
+      const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
+      __builtin_amdgcn_s_barrier();                 // this chunk's image and weights are complete and visible
+#if defined(WINO_PROF)
+      const unsigned long long q2 = __builtin_readcyclecounter();
+      pw[0] += q1 - q0; pw[1] += q2 - q1;
+#endif
+      if (c + 1 == nchunk) {
+        if (un < nunits) W4_SETUP_UNIT(un)
+        else {
+          uc = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) upix[j] = padpix;
+        }
+      }
+      W4_CHUNK_SCALARS()
+      float t_[4][8];
+      {
+        float ra[4][8], rb[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 x0_ = *reinterpret_cast<const f32x4*>(lds + poff[j] + offA);
+          const f32x4 x1_ = *reinterpret_cast<const f32x4*>(lds + (poff[j] ^ 16) + offA);
+          const f32x4 y0_ = *reinterpret_cast<const f32x4*>(lds + poff[j] + offB);
+          const f32x4 y1_ = *reinterpret_cast<const f32x4*>(lds + (poff[j] ^ 16) + offB);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ra[j][k] = x0_[k]; ra[j][4 + k] = x1_[k]; rb[j][k] = y0_[k]; rb[j][4 + k] = y1_[k]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t_[j][k] = fmaf(sg, rb[j][k], ra[j][k]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // every wave holds its patch rows in registers: the image may be overwritten
+#if defined(WINO_PROF)
+      const unsigned long long q3 = __builtin_readcyclecounter();
+      pw[5] += q3 - q2;
+#endif
+      W4_ISSUE_A()
+      const char* const wb = lds + W4_OFF + stg * W4_BYTES + fw;
+#define W4_V(NU, K) (((NU) == 0) ? t_[0][K] - t_[2][K] : ((NU) == 1) ? t_[1][K] + t_[2][K] : ((NU) == 2) ? t_[1][K] - t_[2][K] : t_[1][K] - t_[3][K])
+#if defined(WINO_ABL) && (WINO_ABL & 16)
+#define W4_MFMA(P, N, WW, VX) asm volatile("" :: "v"(WW), "v"(VX));
+#else
+#define W4_MFMA(P, N, WW, VX) acc[P][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P][N], 0, 0, 0);
+#endif
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        float v_[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v_[k] = W4_V(nu, k);
+        u32x4 vh_, vl_;
+        split8(v_, vh_, vl_);
+        const f16x8 w00 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 0) * 2 + 0) * 1024);
+        const f16x8 w01 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 0) * 2 + 1) * 1024);
+        const f16x8 w10 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 1) * 2 + 0) * 1024);
+        const f16x8 w11 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 1) * 2 + 1) * 1024);
+        W4_MFMA(nu, 0, w00, vh_)
+        W4_MFMA(nu, 1, w10, vh_)
+        W4_MFMA(nu, 0, w01, vh_)
+        W4_MFMA(nu, 1, w11, vh_)
+        W4_MFMA(nu, 0, w00, vl_)
+        W4_MFMA(nu, 1, w10, vl_)
+        if (nu == 0) { W4_ISSUE_W(2, 5, stg ^ 1) }
+        else if (nu == 1) { W4_ISSUE_W(5, 8, stg ^ 1) }
+        else if (nu == 2) { W4_ISSUE_W(8, 11, stg ^ 1) }
+      }
+      ++uc;
+#if defined(WINO_PROF)
+      pw[6] += __builtin_readcyclecounter() - q3;
+#endif
+#undef W4_V
+#undef W4_MFMA
+    }
+
+    // ---- epilogue: R[b] = sum_nu M[nu] A[nu][b] per wave (its transform row); the four rows of a tile group meet in LDS
+    // (the weight buffer just consumed), one channel tile per round: wave xi finishes register group q = xi (4 channels
+    // x 2 x 2 pixels per lane) from its own R and the three others': y0 = R0 + R1 + R2, y1 = R1 - R2 - R3.
+#if defined(WINO_PROF)
+    const unsigned long long qe0 = __builtin_readcyclecounter();
+#endif
+    float chk = 0.f;
+    char* const xbuf = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES + tg * (4 * 6144);
+    __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x4 Rm[2];                                  // my own group: R[b][e], r = 4 xi + e
+      if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's inboxes have been read
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 Rq[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          Rq[0][e] = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+          Rq[1][e] = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+        }
+        if (q == xi) { Rm[0] = Rq[0]; Rm[1] = Rq[1]; }
+        else {
+          const int k = (xi < q) ? xi : xi - 1;     // my slot in receiver q's inbox
+          char* const ib = xbuf + q * 6144 + k * 2048 + lane * 16;
+          *reinterpret_cast<f32x4*>(ib) = Rq[0];
+          *reinterpret_cast<f32x4*>(ib + 1024) = Rq[1];
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      f32x4 y[2][2];                                // [a][b]
+      {
+        const float c0m = (xi == 3) ? 0.f : 1.f, c1m = (xi == 0) ? 0.f : (xi == 1) ? 1.f : -1.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { y[0][b] = Rm[b] * c0m; y[1][b] = Rm[b] * c1m; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int x = (k < xi) ? k : k + 1;       // sender's transform row
+          const float c0 = (x == 3) ? 0.f : 1.f, c1 = (x == 0) ? 0.f : (x == 1) ? 1.f : -1.f;
+          const char* const ib = xbuf + xi * 6144 + k * 2048 + lane * 16;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(ib + b * 1024);
+            y[0][b] += o * c0; y[1][b] += o * c1;
+          }
+        }
+      }
+      const int cb = nt * 32 + 8 * xi + 4 * half;
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + cb * 4);
+      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 256 + cb * 4);
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int yy = ey0 + 4 * tg + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
+          const bool ok = yy < H && xx < W;
+          const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            chk = fmaf(y[oa][b][e], 0.f, chk);
+            const float z = fmaf(y[oa][b][e], ms[e], bs[e]);
+            v[e] = fmaxf(z, slope * z);
+          }
+          if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb);
+          if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb);
+          if (ok && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+        }
+    }
+    if (__any(chk != chk)) {
+      if (lane == 0) atomicOr(a.ovf, 1);
+    }
+#if defined(WINO_PROF)
+    pw[3] += __builtin_readcyclecounter() - qe0;
+#endif
+    u = un;
+    if (u >= nunits) break;
+  }
+#if defined(WINO_PROF)
+  if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
+    atomicAdd(a.dbg + 0, pw[0]); atomicAdd(a.dbg + 1, pw[1]); atomicAdd(a.dbg + 2, __builtin_readcyclecounter() - pw_t0);
+    atomicAdd(a.dbg + 3, pw[3]); atomicAdd(a.dbg + 4, 1ull); atomicAdd(a.dbg + 5, pw[5]); atomicAdd(a.dbg + 6, pw[6]);
+  }
+#endif
+#undef W4_SETUP_UNIT
+#undef W4_DMA
+#undef W4_A_SLOT
+#undef W4_ISSUE_A
+#undef W4_ISSUE_W
+#undef W4_CHUNK_SCALARS
+}
+
 static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2) {
   if (a.nsrc < 1 || a.nsrc > 3 || !a.wpack || !a.bias || !a.scale || !a.ovf || !a.zeros || !a.out || a.nchunk < 1) return -1;
   if (a.ntile_n < 1 || a.ntile_n > 2 || (a.cout & 3)) return -6;
@@ -773,22 +1133,29 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (a.res2 && (((a.res2_cs | a.res2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res2) & 15))) return -6;
   if (a.res2 && !a.res1) return -1;
   if ((long long)a.B * a.H * a.W >= (1LL << 24)) return -6;                            // 24-bit pixel index (mul24)
-  const int th = (version == 2) ? v2::TH2 : TH;
+  if (version == 4 && (a.ntile_n != 2 || a.cout != 64)) return -6;
+  const int th = (version == 2) ? v2::TH2 : (version == 4) ? v4::TH4 : TH;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + th - 1) / th;
-  const long long nunits = (long long)a.B * tiles_x * tiles_y * a.ntile_n;
+  const long long nunits = (long long)a.B * tiles_x * tiles_y * (version == 4 ? 1 : a.ntile_n);
   if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
   const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
-  static bool attr[2][3] = {{false, false, false}, {false, false, false}};
+  static bool attr[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
   const int res = a.res2 ? 2 : a.res1 ? 1 : 0;
-  const int ldsb = (version == 2) ? v2::LDS2_BYTES : LDS_BYTES;
+  const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
+  const int vi = (version == 2) ? 1 : (version == 4) ? 2 : 0;
   auto go = [&](auto fn, int threads) {
-    if (!attr[version == 2][res]) {
+    if (!attr[vi][res]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -2;
-      attr[version == 2][res] = true;
+      attr[vi][res] = true;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), ldsb, st, a, (int)nunits);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   };
+  if (version == 4) {
+    if (res == 0) return go(conv_wino4_kernel<0>, 512);
+    if (res == 1) return go(conv_wino4_kernel<1>, 512);
+    return go(conv_wino4_kernel<2>, 512);
+  }
   if (version == 2) {
     if (res == 0) return go(conv_wino2_kernel<0>, 512);
     if (res == 1) return go(conv_wino2_kernel<1>, 512);

@@ -17,7 +17,7 @@ size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs
   }
   if (sum != cin) return 0;
   std::vector<uint16_t> pk;
-  if (!wino::pack_weights_wino(w, cin, cout, pk)) return 0;
+  if (!(cout == 64 ? wino::pack_weights_wino64(w, cin, cout, pk) : wino::pack_weights_wino(w, cin, cout, pk))) return 0;
   out.resize((pk.size() * 2 + 3) / 4);
   memcpy(out.data(), pk.data(), pk.size() * 2);
   return pk.size() * 2;
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restric
       const float x = (float)u;
       const _Float16 hi = (_Float16)x;       // (|x| 2^11 beyond the f16 range becomes inf: the conv raises the range flag)
       const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((float)((u - (double)(float)hi) * 2048.0));
-      const size_t o = ((size_t)(nt * nchunk + c) * wino::W_BYTES) / 2 + (size_t)(((xi * 4 + nu) * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
+      const size_t o = (cout == 64)        // v4 layout: piece ((pos * 2 + ntile) * 2 + plane) of the chunk's 64
+          ? (size_t)c * (wino::W4_BYTES / 2) + (size_t)(((xi * 4 + nu) * 2 + nt) * 2) * 512 + (size_t)h * 256 + (size_t)n * 8 + e
+          : ((size_t)(nt * nchunk + c) * wino::W_BYTES) / 2 + (size_t)(((xi * 4 + nu) * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
       pk[o] = __builtin_bit_cast(uint16_t, p0);
       pk[o + 512] = __builtin_bit_cast(uint16_t, p1);
     }
@@ -89,15 +91,16 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
     ncu = v;
   }
-  // One persistent block per CU walks units of 16 x 32 pixels x 32 channels: a grid of a few rounds with a ragged last one
+  // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of
   // config 2, 800 / 1600 units on 256 CUs = 78 / 89 %, measured equal / slightly better here, stays.)
   {
-    const long long nunits = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 15) / 16) * w.ntile_n;
+    const long long nunits = (w.ntile_n == 2) ? (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8)
+                                              : (long long)a.B * ((a.W + 31) / 32) * ((a.H + 15) / 16);
     const long long rounds = (nunits + ncu - 1) / ncu;
     if (rounds >= 2 && nunits * 100 < rounds * ncu * 75) return HCF_ERR_UNSUPPORTED;
   }
-  const int r = wino::launch(w, ncu, st, 2);
+  const int r = wino::launch(w, ncu, st, w.ntile_n == 2 ? 4 : 2);      // 64 output channels: the two-tile kernel and its pack layout
   return r == 0 ? HCF_OK : r == -6 ? HCF_ERR_UNSUPPORTED : r == -2 ? HCF_ERR_HIP : HCF_ERR_ARG;
 }
 

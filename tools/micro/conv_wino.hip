@@ -85,7 +85,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < w.size(); ++i) w[i] = hashf(i, 3) * 0.5f / sqrtf((float)cin * 9.f);
     for (int i = 0; i < P.cout; ++i) { bias[i] = hashf(i, 5) * 0.1f; scale[i] = 1.f + 0.1f * hashf(i, 6); }
     std::vector<uint16_t> pk;
-    if (!pack_weights_wino(w.data(), cin, P.cout, pk)) { printf("pack failed\n"); return 1; }
+    const int ver = (version == 4 && P.cout != 64) ? 2 : version;         // v4 is the 64-output-channel kernel
+    if (!(ver == 4 ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
@@ -99,7 +100,7 @@ int main(int argc, char** argv) {
     if (P.res) { a.res1 = res; a.res1_cs = 64; a.res1_c0 = 0; a.rs1 = 0.2f; }
     a.ovf = ovf; a.zeros = reinterpret_cast<const char*>(ovf) + 64;
     unsigned long long* dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); a.dbg = dbg;
-    int rc = launch(a, ncu, 0, version);
+    int rc = launch(a, ncu, 0, ver);
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -118,9 +119,9 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) launch(a, ncu, 0, version);
+      for (int i = 0; i < 2; ++i) launch(a, ncu, 0, ver);
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) launch(a, ncu, 0, version);
+      for (int i = 0; i < iters; ++i) launch(a, ncu, 0, ver);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;

@@ -31,6 +31,9 @@ def short_name(k):
         if up == "true":
             tag += "+up"
         return tag
+    m = re.search(r"conv_wino4_kernel<(\d)>", k)
+    if m:
+        return "wino4<%s>" % m.group(1)         # the 64-output-channel Winograd kernel (RDB conv5: 1 or 2 residual inputs)
     m = re.search(r"conv_wino2_kernel<(\d)>", k)
     if m:
         return "wino<%s>" % m.group(1)          # template argument = number of residual inputs (0: conv3 / conv4, 1 / 2: conv5)
