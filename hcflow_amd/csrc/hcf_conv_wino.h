@@ -1034,6 +1034,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
     float chk = 0.f;
     char* const xbuf = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES + tg * (4 * 6144);
     __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
+#if defined(WINO_PROF)
+    pw[7] += __builtin_readcyclecounter() - qe0;    // (skew of the chunk loop: wait for the slowest wave)
+#endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       f32x4 Rm[2];                                  // my own group: R[b][e], r = 4 xi + e
@@ -1092,7 +1095,11 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
           }
           if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb);
           if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb);
+#if defined(WINO_ABL) && (WINO_ABL & 32)     // ablation: no output stores (one lane keeps the values alive)
+          if (ok && cb < a.cout && v[0] == 123.456f) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+#else
           if (ok && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+#endif
         }
     }
     if (__any(chk != chk)) {
@@ -1108,6 +1115,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
     atomicAdd(a.dbg + 0, pw[0]); atomicAdd(a.dbg + 1, pw[1]); atomicAdd(a.dbg + 2, __builtin_readcyclecounter() - pw_t0);
     atomicAdd(a.dbg + 3, pw[3]); atomicAdd(a.dbg + 4, 1ull); atomicAdd(a.dbg + 5, pw[5]); atomicAdd(a.dbg + 6, pw[6]);
+    atomicAdd(a.dbg + 7, pw[7]);
   }
 #endif
 #undef W4_SETUP_UNIT

@@ -129,7 +129,8 @@ int main(int argc, char** argv) {
 #if defined(WINO_PROF)
       { unsigned long long h[8]; CK(hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost));
         if (h[4]) printf("    per wave: life %.0f kcyc (%.2f GHz)  vmcnt %.1f %%  barrier %.1f %%  setup+issue %.1f %%  loads+transform %.1f %%  epilogue %.1f %%\n",
-                         h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 12 * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]); }
+                         h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 12 * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]);
+        if (h[4] && h[7]) printf("    of the epilogue: %.1f %% of the life waiting at its first barrier\n", 100.0 * h[7] / h[2]); }
 #endif
     }
     fflush(stdout);
