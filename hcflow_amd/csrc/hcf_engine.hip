@@ -614,7 +614,7 @@ struct hcf_engine {
       hipEventRecord(prof_events[prof_used].e0, st);
     }
     int r = HCF_ERR_UNSUPPORTED;
-    if (use_f16 && cv.wpack_wino && !fuse2 && !tail && !taping && !wino_stale && !(g_f16x3_ablation & 256)) {
+    if (use_f16 && cv.wpack_wino && !fuse2 && !tail && !wino_stale && !(g_f16x3_ablation & 256)) {
       a.ovf = ovf_flag;
       a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
       r = launch_conv_wino(a, cv.wpack_wino, st);      // HCF_ERR_UNSUPPORTED: this call's views do not qualify
