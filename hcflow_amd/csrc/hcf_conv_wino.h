@@ -697,75 +697,83 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------------
     // In-wave: R[i][b] = sum_nu M[i][nu] A[nu][b]; the pair's partial outputs: xp 0: y0 = R0 + R1, y1 = R1; xp 1 (rows 2, 3):
-    // y0 = R0', y1 = -R0' - R1'. Wave xp finishes channel groups q = 2 xp, 2 xp + 1 (registers r = 4 q + e) and gets the
-    // partner's partials for them through LDS (the stage just consumed: 8 KB per wave).
+    // y0 = R0', y1 = -R0' - R1'. The two waves of a tile group meet in LDS (the stage just consumed), one output row (a) per
+    // round, and the exchange is also a TRANSPOSE: after it lane (patch p of 8, register group q, half) holds the 4 channels
+    // 8 q + 4 half .. + 3 of one patch from both waves, so 8 consecutive lanes cover the 128 contiguous bytes of a pixel's 32
+    // channels (residual loads and stores touch 8 cache lines per instruction instead of 32). Wave xp finishes patches
+    // 16 xp .. 16 xp + 15 of the tile group.
 #if defined(WINO_PROF)
     const unsigned long long qe0 = __builtin_readcyclecounter();
 #endif
     float chk = 0.f;                               // Inf / NaN anywhere in the accumulators reaches a partial output
-    f32x4 mine[2][2][2];                           // [q local][a][b]
     {
-      char* const xb = lds + ((g - 1) & 1) * STAGE2 + tg * 16384 + (xp ^ 1) * 8192 + lane * 16;   // partner's inbox
+      char* const xbuf = lds + ((g - 1) & 1) * STAGE2 + tg * 16384;
+      const int p8 = lane >> 3, qd = (lane >> 1) & 3, hd = lane & 1;            // reader role
+      const int wpos = (half * 32 + ((li + 4 * half) & 31)) * 16;               // writer slot for even q; odd q: + 8 patches (mod 32)
+      const int wpos1 = (half * 32 + ((li + 4 * half + 8) & 31)) * 16;
+      const int cb = ent * 32 + 8 * qd + 4 * hd;
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + cb * 4);
+      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + cb * 4);
       __builtin_amdgcn_s_barrier();                // every wave is done reading the stage
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 y[2][2];
+      for (int oa = 0; oa < 2; ++oa) {
+        // this round's residuals: issued now, used after the exchange
+        f32x4 rv1[2][2], rv2[2][2];
+        size_t pixs[2][2];
+        bool oks[2][2];
+        int rpos[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * q + e;
-          float R[2][2];
+        for (int sgrp = 0; sgrp < 2; ++sgrp) {
+          const int patch = 16 * xp + 8 * sgrp + p8, prow = patch >> 4, pcol = patch & 15;
+          rpos[sgrp] = (hd * 32 + ((patch + 4 * hd + 8 * (qd & 1)) & 31)) * 16 + qd * 1024;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            R[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
-            R[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
-          }
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            y[0][b][e] = xp ? R[0][b] : R[0][b] + R[1][b];
-            y[1][b][e] = xp ? -R[0][b] - R[1][b] : R[1][b];
-            chk = fmaf(y[0][b][e], 0.f, chk);
-            chk = fmaf(y[1][b][e], 0.f, chk);
+          for (int ob = 0; ob < 2; ++ob) {
+            const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
+            oks[sgrp][ob] = yy < H && xx < W;
+            pixs[sgrp][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+            if (RES >= 1) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[sgrp][ob] * a.res1_cs + a.res1_c0 + cb);
+            if (RES == 2) rv2[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[sgrp][ob] * a.res2_cs + a.res2_c0 + cb);
           }
         }
-        const bool keep = (q >> 1) == xp;
-        if (keep) {
+        if (oa == 1) __builtin_amdgcn_s_barrier(); // round 0's buffer has been read
 #pragma unroll
-          for (int aa = 0; aa < 2; ++aa)
+        for (int q = 0; q < 4; ++q) {
+          f32x4 P[2];                              // this wave's contribution to y[oa][b], b = 0 / 1
 #pragma unroll
-            for (int b = 0; b < 2; ++b) mine[q & 1][aa][b] = y[aa][b];
-        } else {
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            float R[2][2];
 #pragma unroll
-          for (int aa = 0; aa < 2; ++aa)
+            for (int i = 0; i < 2; ++i) {
+              R[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+              R[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+            }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(xb + (((q & 1) * 2 + aa) * 2 + b) * 1024) = y[aa][b];
+            for (int bb = 0; bb < 2; ++bb)
+              P[bb][e] = (oa == 0) ? (xp ? R[0][bb] : R[0][bb] + R[1][bb]) : (xp ? -R[0][bb] - R[1][bb] : R[1][bb]);
+          }
+          char* const wbq = xbuf + ((xp * 2) * 4 + q) * 1024 + ((q & 1) ? wpos1 : wpos);
+          *reinterpret_cast<f32x4*>(wbq) = P[0];
+          *reinterpret_cast<f32x4*>(wbq + 4096) = P[1];
         }
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    {
-      const char* const ib = lds + ((g - 1) & 1) * STAGE2 + tg * 16384 + xp * 8192 + lane * 16;
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int ql = 0; ql < 2; ++ql) {
-        const int cb = ent * 32 + 4 * half + 8 * (2 * xp + ql);
-        const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + cb * 4);
-        const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + cb * 4);
+        for (int sgrp = 0; sgrp < 2; ++sgrp)
 #pragma unroll
-        for (int oa = 0; oa < 2; ++oa)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const f32x4 other = *reinterpret_cast<const f32x4*>(ib + ((ql * 2 + oa) * 2 + b) * 1024);
-            const int yy = ey0 + 4 * tg + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
-            const bool ok = yy < H && xx < W;
-            const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+          for (int ob = 0; ob < 2; ++ob) {
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(xbuf + ((0 * 2 + ob) * 4) * 1024 + rpos[sgrp]);
+            const f32x4 y1 = *reinterpret_cast<const f32x4*>(xbuf + ((1 * 2 + ob) * 4) * 1024 + rpos[sgrp]);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float z = fmaf(mine[ql][oa][b][e] + other[e], ms[e], bs[e]);
+              const float yv = y0[e] + y1[e];
+              chk = fmaf(yv, 0.f, chk);
+              const float z = fmaf(yv, ms[e], bs[e]);
               v[e] = fmaxf(z, slope * z);           // none / relu / leaky relu for slope 1 / 0 / 0.2 (a non-finite z trips chk)
+              if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[sgrp][ob][e]);
+              if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[sgrp][ob][e]);
             }
-            if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb);
-            if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb);
-            if (ok && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+            if (oks[sgrp][ob] && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pixs[sgrp][ob] * a.out_cs + a.out_c0 + cb) = v;
           }
       }
     }
@@ -1025,22 +1033,42 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #undef W4_MFMA
     }
 
-    // ---- epilogue: R[b] = sum_nu M[nu] A[nu][b] per wave (its transform row); the four rows of a tile group meet in LDS
-    // (the weight buffer just consumed), one channel tile per round: wave xi finishes register group q = xi (4 channels
-    // x 2 x 2 pixels per lane) from its own R and the three others': y0 = R0 + R1 + R2, y1 = R1 - R2 - R3.
+    // ---- epilogue: R[b] = sum_nu M[nu] A[nu][b] per wave (its transform row). The four rows of a tile group meet in LDS
+    // (the weight buffer just consumed), one channel tile per round, and the exchange is also a TRANSPOSE: after it lane
+    // (patch p of 8, register group q, half) of wave xi holds, for patch 8 xi + p, the 4 channels 8 q + 4 half .. + 3 of all four
+    // rows -> y0 = R0 + R1 + R2, y1 = R1 - R2 - R3, and 8 consecutive lanes cover 128 contiguous bytes of one pixel
+    // (residual loads and stores touch 8 cache lines per instruction instead of 32).
 #if defined(WINO_PROF)
     const unsigned long long qe0 = __builtin_readcyclecounter();
 #endif
     float chk = 0.f;
-    char* const xbuf = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES + tg * (4 * 6144);
+    char* const xbuf = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES + tg * 32768;
+    const int p8 = lane >> 3, qd = (lane >> 1) & 3, hd = lane & 1;              // reader role
+    const int patch = 8 * xi + p8, prow = patch >> 4, pcol = patch & 15;
+    const int wpos = (half * 32 + ((li + 4 * half) & 31)) * 16;                 // writer slot for even q; odd q: + 8 patches (mod 32)
+    const int wpos1 = (half * 32 + ((li + 4 * half + 8) & 31)) * 16;
+    const int rpos = (hd * 32 + ((patch + 4 * hd + 8 * (qd & 1)) & 31)) * 16 + qd * 1024;
     __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
 #if defined(WINO_PROF)
     pw[7] += __builtin_readcyclecounter() - qe0;    // (skew of the chunk loop: wait for the slowest wave)
 #endif
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      f32x4 Rm[2];                                  // my own group: R[b][e], r = 4 xi + e
-      if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's inboxes have been read
+      const int cb = nt * 32 + 8 * qd + 4 * hd;
+      f32x4 rv1[2][2], rv2[2][2];                   // this round's residuals: issued now, used after the exchange
+      size_t pixs[2][2];
+      bool oks[2][2];
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
+          oks[oa][ob] = yy < H && xx < W;
+          pixs[oa][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+          if (RES >= 1) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[oa][ob] * a.res1_cs + a.res1_c0 + cb);
+          if (RES == 2) rv2[oa][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[oa][ob] * a.res2_cs + a.res2_c0 + cb);
+        }
+      if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's buffer has been read
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 Rq[2];
@@ -1050,55 +1078,36 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
           Rq[0][e] = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
           Rq[1][e] = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
         }
-        if (q == xi) { Rm[0] = Rq[0]; Rm[1] = Rq[1]; }
-        else {
-          const int k = (xi < q) ? xi : xi - 1;     // my slot in receiver q's inbox
-          char* const ib = xbuf + q * 6144 + k * 2048 + lane * 16;
-          *reinterpret_cast<f32x4*>(ib) = Rq[0];
-          *reinterpret_cast<f32x4*>(ib + 1024) = Rq[1];
-        }
+        char* const wbq = xbuf + ((xi * 2) * 4 + q) * 1024 + ((q & 1) ? wpos1 : wpos);
+        *reinterpret_cast<f32x4*>(wbq) = Rq[0];
+        *reinterpret_cast<f32x4*>(wbq + 4096) = Rq[1];
       }
       __builtin_amdgcn_s_barrier();
-      f32x4 y[2][2];                                // [a][b]
-      {
-        const float c0m = (xi == 3) ? 0.f : 1.f, c1m = (xi == 0) ? 0.f : (xi == 1) ? 1.f : -1.f;
+      f32x4 R[4][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { y[0][b] = Rm[b] * c0m; y[1][b] = Rm[b] * c1m; }
+      for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int x = (k < xi) ? k : k + 1;       // sender's transform row
-          const float c0 = (x == 3) ? 0.f : 1.f, c1 = (x == 0) ? 0.f : (x == 1) ? 1.f : -1.f;
-          const char* const ib = xbuf + xi * 6144 + k * 2048 + lane * 16;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(ib + b * 1024);
-            y[0][b] += o * c0; y[1][b] += o * c1;
-          }
-        }
-      }
-      const int cb = nt * 32 + 8 * xi + 4 * half;
+        for (int bb = 0; bb < 2; ++bb) R[x][bb] = *reinterpret_cast<const f32x4*>(xbuf + ((x * 2 + bb) * 4) * 1024 + rpos);
       const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + cb * 4);
       const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 256 + cb * 4);
 #pragma unroll
       for (int oa = 0; oa < 2; ++oa)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int yy = ey0 + 4 * tg + 2 * trow + oa, xx = ex0 + 2 * tcol + b;
-          const bool ok = yy < H && xx < W;
-          const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+        for (int ob = 0; ob < 2; ++ob) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            chk = fmaf(y[oa][b][e], 0.f, chk);
-            const float z = fmaf(y[oa][b][e], ms[e], bs[e]);
+            const float yv = oa ? (R[1][ob][e] - R[2][ob][e]) - R[3][ob][e] : (R[0][ob][e] + R[1][ob][e]) + R[2][ob][e];
+            chk = fmaf(yv, 0.f, chk);
+            const float z = fmaf(yv, ms[e], bs[e]);
             v[e] = fmaxf(z, slope * z);
+            if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
+            if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
           }
-          if (RES >= 1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cb);
-          if (RES == 2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cb);
 #if defined(WINO_ABL) && (WINO_ABL & 32)     // ablation: no output stores (one lane keeps the values alive)
-          if (ok && cb < a.cout && v[0] == 123.456f) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+          if (oks[oa][ob] && cb < a.cout && v[0] == 123.456f) *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
 #else
-          if (ok && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cb) = v;
+          if (oks[oa][ob] && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
 #endif
         }
     }

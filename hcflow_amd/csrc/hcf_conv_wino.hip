@@ -1,7 +1,9 @@
 // Winograd F(2x2, 3x3) form of the f16x3 convolution (hcf_conv_wino.h) behind the engine's ConvArgs: used for plain 3x3
-// convs whose source windows are multiples of 16 channels, with >= 128 input channels and 32 / 64 output channels -- the
-// deep convs of the residual dense blocks (RRDBNet_arch.py:18-34), where it beats the direct kernel (profiles/r02_notes.md).
+// convs whose source windows are multiples of 16 channels, with >= 64 input channels and 32 / 64 output channels -- the
+// convs of the residual dense blocks and the 64 -> 64 trunk convs (RRDBNet_arch.py:18-34, 84-97), where it beats the direct
+// kernel (profiles/r02_notes.md).
 #include "hcf_common.h"
+#include <cstdlib>
 #include "hcf_conv_wino.h"
 
 namespace hcf {
@@ -9,7 +11,8 @@ namespace hcf {
 // w: PyTorch [cout][cin][3][3]; bytes of the pack (or 0 when the layer is not eligible / a weight leaves the f16 range)
 size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out) {
   out.clear();
-  if (!w || cin < 128 || (cout != 32 && cout != 64) || nsrc < 1 || nsrc > 3) return 0;
+  static const int min_cin = getenv("HCF_WINO_MIN_CIN") ? atoi(getenv("HCF_WINO_MIN_CIN")) : 64;    // experiment knob, read once (bench A/B: 128 -> 112.2, 96 -> 113.5, 64 -> 114.5 img/s)
+  if (!w || cin < min_cin || (cout != 32 && cout != 64) || nsrc < 1 || nsrc > 3) return 0;
   int sum = 0;
   for (int i = 0; i < nsrc; ++i) {
     if (srcs[i] < 16 || (srcs[i] & 15)) return 0;
