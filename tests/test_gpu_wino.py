@@ -1,6 +1,6 @@
 """-m gpu: the Winograd F(2x2, 3x3) form of the f16x3 convolution (hcf_conv_wino.h / hcf_conv_wino.hip), which the engine
-and the op entry use for plain 3x3 convs with >= 128 input channels in 16-channel-aligned source windows and 32 / 64 output
-channels (the deep convs of the residual dense blocks, RRDBNet_arch.py:18-34): fp32-class accuracy against an fp64
+and the op entry use for plain 3x3 convs with >= 64 input channels in 16-channel-aligned source windows and 32 / 64 output
+channels (the convs of the residual dense blocks and the 64 -> 64 trunk convs, RRDBNet_arch.py:18-34, 84-97): fp32-class accuracy against an fp64
 evaluation, agreement with the direct f16x3 kernel, range reporting, and that the engine really takes it."""
 import ctypes as C
 
@@ -20,6 +20,9 @@ WINO_CASES = [
     (1, 33, 70, [64, 128], 64, None, 2),            # ... and with the RRDB skip as second residual
     (1, 8, 8, [128], 32, "relu", 0),                # a single unit, one source
     (3, 48, 64, [160], 32, "lrelu", 0),             # several units per block
+    (2, 20, 36, [64], 32, "lrelu", 0),              # RDB conv1 (the smallest eligible K: 4 chunks)
+    (1, 16, 32, [64, 32], 32, "lrelu", 0),          # RDB conv2: a 32-channel second source
+    (2, 24, 32, [64], 64, None, 0),                 # trunk conv 64 -> 64 (v4 with 4 chunks)
 ]
 
 
