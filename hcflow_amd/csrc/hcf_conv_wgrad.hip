@@ -523,7 +523,10 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
   if (a.g_max) {
     // f16 matrix cores (one-time opt-in to > 64 KB of dynamic LDS per instantiation)
-    static bool attr[4] = {false, false, false, false};
+    static bool attr_dev[64][4] = {};     // per device: several GPUs in one process (nn.DataParallel replicas)
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
+    bool (&attr)[4] = attr_dev[dev_];
     auto go = [&](auto fn, int idx, int ldsb) {
       if (!attr[idx]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return false;

@@ -1156,7 +1156,11 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   const long long nunits = (long long)a.B * tiles_x * tiles_y * (version == 4 ? 1 : a.ntile_n);
   if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
   const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
-  static bool attr[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
+  // (the opt-in to > 64 KB of dynamic LDS is per device: several GPUs in one process, e.g. nn.DataParallel replicas)
+  static bool attr_dev[64][3][3] = {};
+  int dev_ = 0;
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return -2;
+  bool (&attr)[3][3] = attr_dev[dev_];
   const int res = a.res2 ? 2 : a.res1 ? 1 : 0;
   const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
   const int vi = (version == 2) ? 1 : (version == 4) ? 2 : 0;
