@@ -16,7 +16,7 @@
 //   wave (xi, tg): transform row xi = 0..3 of tile group tg = 0 / 1 (4 output rows x 32 columns = 32 patches = the MFMA N);
 //   it reads the 2 patch rows x 4 columns its row of B^T touches, forms V[xi][0..3] for 8 channels per lane (the MFMA B
 //   fragment layout: lane = (patch, k-half)), and accumulates M[xi][nu] in 4 accumulators. Operand roles are swapped as in
-//   hcf_conv_s16.h (A = weights): a lane ends up with 16 output channels of ONE patch.
+//   tools/micro/hcf_conv_s16.h (A = weights): a lane ends up with 16 output channels of ONE patch.
 //   LDS: two stages of {10 x 34 halo pixels x 16 channels fp32 (16-byte slots XOR-swizzled inside each 256-byte bank row:
 //   conflict-free patch reads), 32 KB of transformed weights [pos][plane][k-half][32 oc][8]}, filled by global_load_lds
 //   one chunk ahead (the next unit's first chunk during the last chunk of the current one); one barrier per chunk.

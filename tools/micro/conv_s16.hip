@@ -1,4 +1,4 @@
-// Stand-alone development harness for the split16 / LDS-DMA 3x3 convolution (hcflow_amd/csrc/hcf_conv_s16.hip):
+// Stand-alone development harness for the split16 / LDS-DMA 3x3 convolution (tools/micro/hcf_conv_s16.h; build with -I tools/micro -I hcflow_amd/csrc):
 // builds the kernel header against synthetic RDB-shaped problems, checks it against a naive fp64 evaluation of the
 // same split operands, and times the RDB shapes of config 2 (B = 16, 320^2 / 160^2).
 //   hipcc -O3 --offload-arch=gfx950 -I hcflow_amd/csrc tools/micro/conv_s16.hip -o build/micro/conv_s16 && build/micro/conv_s16
