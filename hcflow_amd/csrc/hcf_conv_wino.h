@@ -159,6 +159,7 @@ __device__ __forceinline__ int a_off(int px, int part) {
   return R * 256 + ((sl ^ ((R & 7) << 1)) << 4);
 }
 
+#if defined(WINO_WITH_V1)          // the first kernel of the series: kept for tools/micro/conv_wino.hip, not part of the library
 template <int RES>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const Args a, const int nunits) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -432,6 +433,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const Args a, const i
   }
 #endif
 }
+
+#endif  // WINO_WITH_V1
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v3: 16 x 32-pixel unit, 8 waves = 4 tile groups x 2 transform-row pairs, TWO waves per SIMD (256 registers per lane: the 8
@@ -1182,9 +1185,13 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
     if (res == 1) return go(conv_wino2_kernel<1>, 512);
     return go(conv_wino2_kernel<2>, 512);
   }
+#if defined(WINO_WITH_V1)
   if (res == 0) return go(conv_wino_kernel<0>, 512);
   if (res == 1) return go(conv_wino_kernel<1>, 512);
   return go(conv_wino_kernel<2>, 512);
+#else
+  return -6;
+#endif
 }
 #endif  // __HIPCC__
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#define WINO_WITH_V1 1
 #include "hcf_conv_wino.h"
 
 using namespace hcf::wino;
