@@ -26,7 +26,8 @@ The JSON line also carries
                 matrix) from MI355X_MICROARCH.md; traffic = HBM bytes per launch from a separate rocprofv3 --pmc run,
                 REPLAYED from profiles/ (marked as such) or null
   cpu_baseline  the CPU oracle (oracle/hcflow_oracle.py, a PyTorch-CPU port of the reference path) on this host:
-                BASELINE config 1 (B=1, tau=0, same LR size), median of >= 3 timed passes, rank 0, N = 1 only.
+                BASELINE config 1 (B=1, tau=0, same LR size), median of >= 5 timed passes, rank 0, N = 1 only; its output is
+                kept and compared with the engine's on the same LR (precision.check.max_abs_diff_vs_cpu_path).
 """
 import argparse
 import contextlib
@@ -75,7 +76,7 @@ def main():
     ap.add_argument("--no-other-precision", action="store_true", help="skip the timed run of the other precision")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the f16x3-vs-exact deviation check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--cpu-passes", type=int, default=5)
     args = ap.parse_args()
 
     import torch
@@ -243,7 +244,20 @@ def main():
         img_s = world * B * args.steps / dt
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cfg, params, h, args.cpu_passes)
+            cpu, cpu_lr, cpu_out = cpu_baseline(cfg, params, h, args.cpu_passes)
+            # DIRECT parity at full size: the oracle's config-1 output (B=1, tau=0, this LR size) against the engine on the same
+            # LR, both conv precisions, outside the timed region (north_star: within 1e-4 of the CPU path)
+            with torch.no_grad():
+                for mode in ("exact", "f16x3"):
+                    net.set_precision(mode)
+                    y = net(lr=cpu_lr.to(dev), z=None, u=None, eps_std=0.0, reverse=True)
+                    torch.cuda.synchronize()
+                    if check is None:
+                        check = {"tolerance": 1e-4}
+                    check.setdefault("max_abs_diff_vs_cpu_path", {})[mode] = float((y.cpu() - cpu_out).abs().max())
+                net.set_precision(default_mode)
+                check["cpu_path"] = ("oracle/hcflow_oracle.py (pinned to the reference by tests/golden): BASELINE config 1, "
+                                     "B=1 LR %dx%d, tau=0, full depth, same weights" % (h, h))
         line = {
             "metric": ("HR images/sec (inverse sample) DIV2K x4 160px LR" if cfg.sr else
                        "HR images/sec (rescaling x4 forward + inverse round trip)"), "value": round(img_s, 4),
@@ -260,6 +274,7 @@ def main():
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
             "precision": {"mode": default_mode, "is_module_default": default_mode == "f16x3",
+                          "range_check": net._range_check[0],
                           "note": "value / roofline are the module's default mode; `other_precision` is the same workload, same "
                                   "number of timed steps, on the other conv kernels",
                           "check": check},
@@ -272,12 +287,12 @@ def main():
 
 def cpu_baseline(cfg, params, h, passes):
     """Oracle (PyTorch-CPU port of the reference path) on this host: BASELINE.json config 1 -- one B=1 LR patch of the same
-    size, tau = 0, same weights -- `passes` (>= 3) timed passes after a warm-up, median. tau does not change the work.
+    size, tau = 0, same weights -- `passes` (>= 5) timed passes after a warm-up, median. tau does not change the work.
     The oracle is only the thing MEASURED AGAINST, never the product."""
     import statistics
     import torch
     from oracle import hcflow_oracle as O
-    passes = max(3, int(passes))
+    passes = max(5, int(passes))
     g = torch.Generator().manual_seed(0)
     lr = torch.rand(1, 3, h, h, generator=g)
     fn = O.sr_inverse if cfg.sr else O.rescale_inverse
@@ -301,7 +316,7 @@ def cpu_baseline(cfg, params, h, passes):
         fn(lr[:, :, :h // 2, :h // 2].contiguous(), params, cfg, 0.0)   # warm-up (oneDNN primitives)
         for _ in range(passes):
             t0 = time.perf_counter()
-            fn(lr, params, cfg, 0.0)
+            out = fn(lr, params, cfg, 0.0)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     cpu_model = ""
@@ -312,10 +327,11 @@ def cpu_baseline(cfg, params, h, passes):
                 break
     except OSError:
         pass
-    return {"value": round(1.0 / med, 4), "unit": "HR images/s", "cores": threads, "kind": "port",
+    return ({"value": round(1.0 / med, 4), "unit": "HR images/s", "cores": threads, "kind": "port",
             "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN): BASELINE config 1, B=1 LR %dx%d, tau=0, median of %d "
                       "timed passes after warm-up, %d threads chosen from %s on a %d-CPU host" % (h, h, passes, threads, cands, ncpu),
-            "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times]}
+            "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times],
+             "spread_rel": round((max(times) - min(times)) / med, 3)}, lr, out)
 
 
 if __name__ == "__main__":

@@ -407,7 +407,7 @@ class _EngineModule(nn.Module):
     def check_range(self) -> bool:
         """"lazy" mode: True if an f16x3 pass since the last check overflowed the f16 range (its outputs are invalid and
         must be recomputed with set_precision("exact")). Waits for the enqueued passes."""
-        return any(ent["engine"].check_range() for ent in self._engines.values())
+        return any([ent["engine"].check_range() for ent in self._engines.values()])   # every engine's flag is read AND cleared
 
     def invalidate(self):
         """Force a repack of every engine on its next call. Needed after writes the version counters do not see
@@ -641,10 +641,13 @@ class _EngineModule(nn.Module):
             flags |= _lib.FLAG_NO_RANGE_CHECK
         if cache_cond:
             # the caller's tensor identity + version stand for its contents; any parameter change drops the key (_engine_for)
+            # The keyed tensor is HELD while its key is live: a freed tensor's address is handed to the next same-shape batch
+            # by the caching allocator (with _version 0 again), which would otherwise hit the key with other contents.
             key = (lr_in.data_ptr(), lr_in._version, tuple(lr_in.shape), str(lr_in.dtype), str(lr_in.device))
-            flags |= _lib.FLAG_REUSE_COND if self._cond_key.get(idx) == key else _lib.FLAG_KEEP_COND
-            self._cond_key[idx] = key
-            keep.append(lr_in)
+            have = self._cond_key.get(idx)
+            hit = have is not None and have[0] == key and have[1] is lr_in
+            flags |= _lib.FLAG_REUSE_COND if hit else _lib.FLAG_KEEP_COND
+            self._cond_key[idx] = (key, lr_in)
         else:
             self._cond_key.pop(idx, None)
         stream = self._stream(idx)

@@ -88,12 +88,15 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   }
   w.ovf = a.ovf;
   w.zeros = reinterpret_cast<const char*>(a.zeros);
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    ncu = v;
+  static int ncu_dev[64] = {0};               // per device (a process may drive several GPUs: nn.DataParallel replicas)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!ncu_dev[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    ncu_dev[dev] = v;
   }
+  const int ncu = ncu_dev[dev];
   // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of
   // config 2, 800 / 1600 units on 256 CUs = 78 / 89 %, measured equal / slightly better here, stays.)

@@ -1130,6 +1130,11 @@ struct hcf_engine {
     if (use_f16 && !ovf_flag) {
       if (hipMalloc((void**)&ovf_flag, 256) != hipSuccess) return fail(HCF_ERR_NOMEM, "hipMalloc failed for the overflow flag");
       if (hipMemsetAsync(ovf_flag, 0, 256, st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+      ovf_clear = false;
+    }
+    if (use_f16 && ovf_clear) {      // a read flag is cleared on the stream of the NEXT pass (not on the stream of the last one)
+      if (hipMemsetAsync(ovf_flag, 0, sizeof(int), st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+      ovf_clear = false;
     }
     body();
     if (use_f16 && rc == HCF_OK && !(pass_flags & HCF_FLAG_NO_RANGE_CHECK)) {
@@ -1152,18 +1157,30 @@ struct hcf_engine {
   // HCF_PRECISION_EXACT); 0: none. Waits for the passes enqueued so far.
   int check_range(int* overflowed) {
     if (overflowed) *overflowed = 0;
+    if (ovf_latch() != HCF_OK) return rc;
+    if (ovf_sticky) {
+      if (overflowed) *overflowed = 1;
+      n_fallbacks++;
+      ovf_sticky = false;
+    }
+    return HCF_OK;
+  }
+  // Fold the pending read-back of the device flag into the host-side latch. Called by check_range and before anything that
+  // clears the device flag for its own use (taped passes, backward passes), so an unread overflow of an earlier inference pass
+  // is never lost.
+  int ovf_latch() {
     if (!ovf_pending) return HCF_OK;
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     if (hipEventSynchronize(ovf_ev) != hipSuccess) return fail(HCF_ERR_HIP, "hipEventSynchronize failed");
     ovf_pending = false;
     if (*ovf_host) {
-      if (overflowed) *overflowed = 1;
-      n_fallbacks++;
+      ovf_sticky = true;
       *ovf_host = 0;
-      if (hipMemsetAsync(ovf_flag, 0, sizeof(int), st) != hipSuccess) return fail(HCF_ERR_HIP, "hipMemsetAsync failed");
+      ovf_clear = true;
     }
     return HCF_OK;
   }
+  bool ovf_sticky = false, ovf_clear = false;
   uint32_t pass_flags = 0;
 };
 

@@ -258,11 +258,19 @@ int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const 
     wa.part = t.dev(wa.part_cap);
     if (!t.ok) return HCF_ERR_NOMEM;
     if (rc == HCF_OK && g_op_precision == PREC_F16X3) {        // f16 matrix cores: g is scaled by a power of two from max |g|
-      float* gm = t.dev(1);
+      float* gm = t.dev(2);
       if (!t.ok) return HCF_ERR_NOMEM;
-      if (hipMemsetAsync(gm, 0, sizeof(float), st) != hipSuccess) return HCF_ERR_HIP;
+      if (hipMemsetAsync(gm, 0, 2 * sizeof(float), st) != hipSuccess) return HCF_ERR_HIP;
       rc = launch_absmax(gv, B, H, W, gm, st);
-      wa.g_max = gm;
+      // X is split without a scale: an |x| beyond the f16 range (nothing range-checked this caller's tensor) would turn the
+      // hi part into inf -> the fp32 weight-gradient kernel takes such inputs
+      for (int i = 0; i < n_src && rc == HCF_OK; ++i)
+        rc = launch_absmax(wa.src[i], B, H >> wa.src[i].up, W >> wa.src[i].up, gm + 1, st);
+      float xmax = 0.f;
+      if (rc == HCF_OK && (hipMemcpyAsync(&xmax, gm + 1, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                           hipStreamSynchronize(st) != hipSuccess))
+        rc = HCF_ERR_HIP;
+      if (xmax < 65504.f) wa.g_max = gm;           // NaN / inf compare false -> fp32 kernel
     }
     if (rc == HCF_OK) rc = launch_conv_wgrad(wa, st);
     if (rc == HCF_OK && hipMemcpyAsync(dw, wa.dw, nw * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) rc = HCF_ERR_HIP;

@@ -1,0 +1,123 @@
+"""-m gpu: DIRECT full-size parity of the HIP path (both conv precisions) against the CPU oracle.
+
+north_star: "outputs match the reference PyTorch CPU path on the same LR/z inputs within 1e-4 fp32". The net fixtures pin the
+oracle to the reference at small LR sizes; these tests run the FULL-DEPTH nets at the BASELINE.json sizes (configs 1-4: LR
+160x160 for SR x4, 20x20 for Face x8, HR 640x640 for rescaling) through the CPU oracle and the engine on the same seeded LR
+and eps and compare directly (no transitive f16x3-vs-exact chain). Reference shape: HCFlowNet_SR_arch.py:70-75,
+FlowNet_SR_x4.py:106-123, FlowNet_SR_x8.py:121-144, FlowNet_Rescaling_x4.py:111-128.
+
+Tolerance: 1e-4 * max(1, max|ref|) on the un-clamped output (and 1e-4 absolute after the clamp to [0, 1]); NLL within 1e-4
+bits/dim (BASELINE.json metric). The oracle passes take 5-30 s each on the GPU box's host cores.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hcflow_oracle as O
+from hcflow_amd.config import preset, eps_shapes
+from tests.util import cached_params, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+_nets = {}
+
+
+def _net(name, seed):
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    key = (name, seed)
+    if key not in _nets:
+        _nets.clear()
+        torch.cuda.empty_cache()
+        cfg = preset(name)
+        p = cached_params(name, seed)
+        net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(p, strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        _nets[key] = (cfg, p, net.to("cuda:0").eval())
+    return _nets[key]
+
+
+def _threads():
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))     # 16 is the fastest setting for this op mix (bench.py)
+
+
+def _check_inverse(cfg, p, net, lr, tau, eps, label):
+    """Both precisions against one oracle pass; returns the f16x3 deviation for the log."""
+    _threads()
+    with torch.no_grad():
+        fn = O.sr_inverse if cfg.sr else O.rescale_inverse
+        ref_raw = fn(lr, p, cfg, tau, eps, clamp=False)
+        scale = max(1.0, float(ref_raw.abs().max()))
+        devs = {}
+        for mode in ("exact", "f16x3"):
+            net.set_precision(mode)
+            raw = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=tau, eps=eps, clamp=False)
+            out = net(lr=lr.cuda(), z=None, u=None, eps_std=tau, reverse=True, eps=eps)
+            d_raw, d_out = maxdiff(raw, ref_raw), maxdiff(out, ref_raw.clamp(0, 1))
+            devs[mode] = d_raw
+            assert d_raw <= 1e-4 * scale, (label, mode, d_raw, scale)
+            assert d_out <= 1e-4, (label, mode, d_out)
+            assert net.engine().fallback_count() == 0, (label, mode, "f16x3 range fallback on the seeded weights")
+    print("full-size parity %s: max|HIP - CPU oracle| exact %.2e, f16x3 %.2e (scale %.2f)" % (label, devs["exact"], devs["f16x3"], scale))
+    net.set_precision("exact")
+    return devs
+
+
+@pytest.mark.parametrize("B,tau", [(1, 0.0), (2, 0.8)])
+def test_sr4_inverse_full_size_vs_cpu_oracle(B, tau):
+    """BASELINE configs 1 / 2: SR_DF2K_4X (K=26, RRDB 7+7), LR 160x160 -> HR 640x640."""
+    cfg, p, net = _net("SR_DF2K_4X", 1234)
+    g = torch.Generator().manual_seed(160 + B)
+    lr = torch.rand(B, 3, 160, 160, generator=g)
+    eps = [torch.randn(s, generator=g) * tau for s in eps_shapes(cfg, B, 160, 160)] if tau > 0 else None
+    _check_inverse(cfg, p, net, lr, tau, eps, "SR_DF2K_4X B=%d LR 160x160 tau=%.1f" % (B, tau))
+
+
+def test_sr4_nll_full_size_vs_cpu_oracle():
+    """NLL (bits/dim) of the full-depth x4 net on HR 160x160 patches (train GT_size) within 1e-4 bits/dim."""
+    cfg, p, net = _net("SR_DF2K_4X", 1234)
+    _threads()
+    g = torch.Generator().manual_seed(77)
+    hr = torch.rand(2, 3, 160, 160, generator=g)
+    noise = torch.rand(2, 3, 160, 160, generator=g)
+    with torch.no_grad():
+        lr_ref, _ = O.sr_forward(hr, torch.zeros(2, 3, 40, 40), p, cfg, noise=noise)   # LR^ of the oracle: the self-consistent target
+        _, nll_ref = O.sr_forward(hr, lr_ref, p, cfg, noise=noise)
+        for mode in ("exact", "f16x3"):
+            net.set_precision(mode)
+            lr_hat, nll = net(hr=hr.cuda(), lr=lr_ref.cuda(), reverse=False, noise=noise.cuda())
+            d = (lr_hat.cpu() - lr_ref).abs()
+            assert float(d.max()) <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 0.01, (mode, float(d.max()))
+            assert abs(float(nll) - float(nll_ref)) <= 1e-4, (mode, float(nll), float(nll_ref))
+    net.set_precision("exact")
+
+
+def test_sr8_inverse_full_size_vs_cpu_oracle():
+    """BASELINE config 3: SR_CelebA_8X, LR 20x20 -> HR 160x160, tau sweep member 0.8."""
+    cfg, p, net = _net("SR_CelebA_8X", 1234)
+    g = torch.Generator().manual_seed(20)
+    lr = torch.rand(2, 3, 20, 20, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.8 for s in eps_shapes(cfg, 2, 20, 20)]
+    _check_inverse(cfg, p, net, lr, 0.8, eps, "SR_CelebA_8X B=2 LR 20x20 tau=0.8")
+
+
+def test_rescaling_roundtrip_full_size_vs_cpu_oracle():
+    """BASELINE config 4: Rescaling_DF2K_4X, HR 640x640 -> LR 160x160 -> Quant -> HR 640x640, every leg against the oracle."""
+    cfg, p, net = _net("Rescaling_DF2K_4X", 1234)
+    _threads()
+    g = torch.Generator().manual_seed(640)
+    hr = torch.rand(1, 3, 640, 640, generator=g)
+    with torch.no_grad():
+        lr_ref, z1_ref, z2_ref = O.rescale_forward(hr, p, cfg)
+        lrq = (lr_ref.clamp(0, 1) * 255.).round() / 255.
+        for mode in ("exact", "f16x3"):
+            net.set_precision(mode)
+            lr_hat, z1, z2 = net(hr=hr.cuda(), reverse=False)
+            assert maxdiff(lr_hat, lr_ref) <= 1e-4, (mode, maxdiff(lr_hat, lr_ref))
+            assert maxdiff(z1, z1_ref) <= 1e-4 * max(1.0, float(z1_ref.abs().max())), (mode, maxdiff(z1, z1_ref))
+            assert maxdiff(z2, z2_ref) <= 1e-4 * max(1.0, float(z2_ref.abs().max())), (mode, maxdiff(z2, z2_ref))
+    eps = [torch.randn(s, generator=g) for s in eps_shapes(cfg, 1, 160, 160)]
+    _check_inverse(cfg, p, net, lrq, 1.0, eps, "Rescaling_DF2K_4X B=1 HR 640x640 decode")
