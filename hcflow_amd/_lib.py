@@ -32,6 +32,7 @@ SYMBOLS = [
     "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
     "hcf_train_select_tape", "hcf_train_forward_rescale", "hcf_train_backward_rescale",
+    "hcf_debug_range_probe", "hcf_debug_range_probe_read",
 ]
 
 
@@ -102,6 +103,8 @@ def load() -> C.CDLL:
     lib.hcf_train_select_tape.argtypes = [vp, i32]
     lib.hcf_train_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, C.c_uint32, vp]
     lib.hcf_train_backward_rescale.argtypes = [vp, fp, fp, fp, fp, i64, vp]
+    lib.hcf_debug_range_probe.argtypes = [vp, i32]
+    lib.hcf_debug_range_probe_read.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(f32), C.POINTER(i32)]
     lib.hcf_bind_param_device.argtypes = [vp, C.c_char_p, fp]
     lib.hcf_refresh_from_device.argtypes = [vp, vp]
     lib.hcf_train_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
@@ -238,6 +241,24 @@ class Engine:
         o = C.c_int32(0)
         check(self.lib.hcf_check_range(self._h, C.byref(o)), self._h, "hcf_check_range")
         return bool(o.value)
+
+    def range_probe(self, enable: bool):
+        check(self.lib.hcf_debug_range_probe(self._h, int(enable)), self._h, "hcf_debug_range_probe")
+
+    def range_probe_records(self):
+        """[(weight key, max|x|, max|V|, cin, cout, H, W, ran_f16x3, has_wino)] in launch order since range_probe(True)."""
+        out, i = [], 0
+        key = C.create_string_buffer(256)
+        mx = (C.c_float * 2)()
+        info = (C.c_int32 * 6)()
+        while True:
+            rc = self.lib.hcf_debug_range_probe_read(self._h, i, key, 256, mx, info)
+            if rc == -4:
+                break
+            check(rc, self._h, "hcf_debug_range_probe_read")
+            out.append((key.value.decode(), float(mx[0]), float(mx[1])) + tuple(int(v) for v in info))
+            i += 1
+        return out
 
     def profile_convs(self, enable: bool):
         check(self.lib.hcf_profile_convs(self._h, int(enable)), self._h, "hcf_profile_convs")

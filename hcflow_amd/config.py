@@ -202,6 +202,14 @@ def preset(name: str) -> NetConfig:
         return NetConfig(kind="Rescaling", scale=4, quant=256.0, L=2, K=[5, 5, 5], after=[2, 2],
                          squeeze="haar", perm="none", coupling="Affine3shift",
                          nn_module="DenseBlock", hidden=32, rrdb_nb=(1, 1), rrdb_gc=16)
+    # narrow variants (RRDB_nf 8, hidden 8) for the checkpoint fixtures: a whole state dict in a few hundred KB
+    if name == "SR_4X_micro":
+        return NetConfig(kind="SR", scale=4, quant=64.0, L=2, K=[3, 3, 3], after=[1, 1], hidden=8, c_hidden=8,
+                         rrdb_nb=(1, 1), rrdb_nf=8, rrdb_gc=4)
+    if name == "Rescaling_4X_micro":
+        return NetConfig(kind="Rescaling", scale=4, quant=256.0, L=2, K=[3, 3, 3], after=[1, 1],
+                         squeeze="haar", perm="none", coupling="Affine3shift",
+                         nn_module="DenseBlock", hidden=8, rrdb_nb=(1, 1), rrdb_nf=8, rrdb_gc=4)
     raise KeyError(name)
 
 

@@ -104,6 +104,7 @@ struct WgradArgs {
 size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);
 int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |g| (out zero-initialised)
+int launch_wino_vmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |B^T d B| over the F(2x2,3x3) patches
 
 // ---- device-side weight repack (hcf_repack.hip) -------------------------------------------------------------------
 struct RepackArgs {

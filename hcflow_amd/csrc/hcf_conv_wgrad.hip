@@ -465,7 +465,49 @@ __global__ __launch_bounds__(256) void absmax_kernel(View g, long long npix, flo
   if (threadIdx.x == 0 && shm) atomicMax(reinterpret_cast<int*>(out), shm);
 }
 
+// max |B^T d B| over every F(2x2,3x3) input patch (4x4 pixels, stride 2, zero padding 1) of a channel window: the largest value
+// the Winograd kernels have to split into f16 hi / lo parts (range probe only, hcf_debug_range_probe)
+__global__ __launch_bounds__(256) void wino_vmax_kernel(View g, int B, int H, int W, float* out) {
+  const int tw = (W + 1) / 2, th = (H + 1) / 2;
+  const long long total = (long long)B * th * tw * g.n;
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % g.n);
+    long long tix = i / g.n;
+    const int tx = (int)(tix % tw);
+    tix /= tw;
+    const int ty = (int)(tix % th), b = (int)(tix / th);
+    float d[4][4], t[4][4];
+    for (int r = 0; r < 4; ++r)
+      for (int q = 0; q < 4; ++q) {
+        const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + q;
+        d[r][q] = (y >= 0 && y < H && x >= 0 && x < W) ? g.p[(((size_t)b * H + y) * W + x) * g.cs + g.c0 + c] : 0.f;
+      }
+    for (int q = 0; q < 4; ++q) {
+      t[0][q] = d[0][q] - d[2][q]; t[1][q] = d[1][q] + d[2][q]; t[2][q] = d[2][q] - d[1][q]; t[3][q] = d[1][q] - d[3][q];
+    }
+    for (int r = 0; r < 4; ++r) {
+      mx = fmaxf(mx, fabsf(t[r][0] - t[r][2])); mx = fmaxf(mx, fabsf(t[r][1] + t[r][2]));
+      mx = fmaxf(mx, fabsf(t[r][2] - t[r][1])); mx = fmaxf(mx, fabsf(t[r][1] - t[r][3]));
+    }
+  }
+  __shared__ int shm;
+  if (threadIdx.x == 0) shm = 0;
+  __syncthreads();
+  if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
+  __syncthreads();
+  if (threadIdx.x == 0 && shm) atomicMax(reinterpret_cast<int*>(out), shm);
+}
+
 }  // namespace wgrad
+
+int launch_wino_vmax(const View& g, int B, int H, int W, float* out, hipStream_t st) {
+  if (!g.p || !out || g.up) return HCF_ERR_ARG;
+  const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * g.n;
+  const unsigned nb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(wgrad::wino_vmax_kernel, dim3(nb), dim3(256), 0, st, g, B, H, W, out);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
 
 int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st) {
   if (!g.p || !out) return HCF_ERR_ARG;

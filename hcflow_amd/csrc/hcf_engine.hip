@@ -613,6 +613,7 @@ struct hcf_engine {
       }
       hipEventRecord(prof_events[prof_used].e0, st);
     }
+    if (probe_on) probe_conv(cv, srcs, H, W);
     int r = HCF_ERR_UNSUPPORTED;
     if (use_f16 && cv.wpack_wino && !fuse2 && !tail && !wino_stale && !(g_f16x3_ablation & 256)) {
       a.ovf = ovf_flag;
@@ -641,6 +642,28 @@ struct hcf_engine {
       prof_used++;
     }
     if (r != HCF_OK) fail(r, "conv launch failed");
+  }
+
+  // ---- range probe (hcf_debug_range_probe): max |x| of every conv's inputs and, for the layers that have a Winograd pack,
+  // max |B^T d B| of the transformed input patches -- the values the f16x3 kernels must split (limit 65504). Debug only.
+  bool probe_on = false;
+  struct ProbeRec { std::string key; int cin, cout, H, W, f16, wino; };
+  std::vector<ProbeRec> probe_recs;
+  float* probe_dev = nullptr;
+  static constexpr int kProbeCap = 16384;
+  void probe_conv(const Conv& cv, const std::vector<View>& srcs, int H, int W) {
+    if ((int)probe_recs.size() >= kProbeCap || !probe_dev) return;
+    float* slot = probe_dev + 2 * probe_recs.size();
+    int cin = 0;
+    for (int i = 0; i < cv.nsrc; ++i) {
+      View v = srcs[i];
+      const int up = v.up;
+      v.up = 0;
+      cin += v.n;
+      launch_absmax(v, B_, H >> up, W >> up, slot, st);
+      if (cv.wpack_wino && up == 0) launch_wino_vmax(v, B_, H, W, slot + 1, st);
+    }
+    probe_recs.push_back({cv.wkey, cin, cv.cout, H, W, (use_f16 && cv.wpack16 && cv.taps == 9) ? 1 : 0, cv.wpack_wino ? 1 : 0});
   }
 
 #define HCF_LAUNCH(expr)                                    \
@@ -1226,6 +1249,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->ovf_host) hipHostFree(e->ovf_host);
   if (e->ovf_ev) hipEventDestroy(e->ovf_ev);
   if (e->stats_dev) hipFree(e->stats_dev);
+  if (e->probe_dev) hipFree(e->probe_dev);
   if (e->garena.base) hipFree(e->garena.base);
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
@@ -1451,6 +1475,31 @@ int hcf_get_param(hcf_engine* e, const char* key, float* out, int64_t numel) {
       return e->fail(HCF_ERR_HIP, "hcf_get_param: D2H copy failed");
   }
   memcpy(out, it->second.data.data(), sizeof(float) * (size_t)numel);
+  return HCF_OK;
+}
+
+int hcf_debug_range_probe(hcf_engine* e, int32_t enable) {
+  if (!e) return HCF_ERR_ARG;
+  if (enable) {
+    if (e->device >= 0 && hipSetDevice(e->device) != hipSuccess) return e->fail(HCF_ERR_HIP, "hipSetDevice failed");
+    if (!e->probe_dev && hipMalloc((void**)&e->probe_dev, sizeof(float) * 2 * hcf_engine::kProbeCap) != hipSuccess)
+      return e->fail(HCF_ERR_NOMEM, "hipMalloc failed for the range probe");
+    if (hipMemset(e->probe_dev, 0, sizeof(float) * 2 * hcf_engine::kProbeCap) != hipSuccess) return e->fail(HCF_ERR_HIP, "hipMemset failed");
+    e->probe_recs.clear();
+  }
+  e->probe_on = enable != 0;
+  return HCF_OK;
+}
+
+int hcf_debug_range_probe_read(hcf_engine* e, int32_t index, char* key, int32_t key_cap, float* maxima, int32_t* info) {
+  if (!e || index < 0 || !key || key_cap < 1 || !maxima || !info) return HCF_ERR_ARG;
+  if (index >= (int)e->probe_recs.size()) return HCF_ERR_KEY;              /* past the last record */
+  if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(maxima, e->probe_dev + 2 * (size_t)index, 2 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    return e->fail(HCF_ERR_HIP, "range probe read-back failed");
+  const auto& r = e->probe_recs[index];
+  snprintf(key, (size_t)key_cap, "%s", r.key.c_str());
+  info[0] = r.cin; info[1] = r.cout; info[2] = r.H; info[3] = r.W; info[4] = r.f16; info[5] = r.wino;
   return HCF_OK;
 }
 

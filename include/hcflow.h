@@ -157,8 +157,10 @@ size_t hcf_weight_bytes(const hcf_engine* e);
  * intermediate tensor in HBM and records the backward pass. hcf_train_backward then writes
  *   d(grad_nll * nll) / d(parameter)   for EVERY parameter, concatenated in hcf_param_info order (= state_dict
  * order, each tensor flattened), into `dparams` (device buffer of `numel` = total parameter count floats); the
- * caller slices it into its .grad tensors. One backward per forward; `lr` must stay alive in between. Exact fp32
- * kernels; the weight-gradient atomics are the only run-to-run non-determinism. SR nets only. */
+ * caller slices it into its .grad tensors. One backward per forward; `lr` must stay alive in between. The convs follow
+ * hcf_set_precision (f16x3: forward, data-gradient and weight-gradient convs on the split kernels, the latter only for
+ * layers whose taped forward was range-checked; exact: fp32 MFMA). Every per-channel and split-K sum is reduced in a fixed
+ * order: the gradients are bit-reproducible run to run (no floating-point atomics). SR nets only. */
 int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr,
                          float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
@@ -270,6 +272,14 @@ int hcf_op_gauss_logp(const float* h, const float* x, float* out_logp, int32_t B
                       hcf_stream_t stream);
 int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t seed, float* out, int32_t B, int32_t C,
                         int32_t H, int32_t W, int32_t rescale, hcf_stream_t stream);
+
+/* Range-headroom probe of the f16x3 path (tools/range_headroom.py): while enabled, every conv launch of the following passes
+ * also records max |x| over its input windows and -- for layers that own a Winograd pack -- max |B^T d B| over the F(2x2,3x3)
+ * input patches, i.e. the values the split has to represent (f16 limit 65504). hcf_debug_range_probe_read returns record
+ * `index` (launch order): key = state-dict key of the conv's weight, maxima[2] = {max |x|, max |V| (0 if not Winograd)},
+ * info[6] = {cin, cout, H, W, ran on f16x3, has a Winograd pack}; HCF_ERR_KEY past the last record. Debug / evidence only. */
+int hcf_debug_range_probe(hcf_engine* e, int32_t enable);
+int hcf_debug_range_probe_read(hcf_engine* e, int32_t index, char* key, int32_t key_cap, float* maxima, int32_t* info);
 
 double hcf_debug_last_clock_mhz(void);
 /* tools/conv_bench.py --ablate: timing-only ablations of the f16x3 kernel (results invalid); 0 = off */

@@ -460,10 +460,205 @@ def gen_op_fixture(ref_sr, ref_rs):
     print("wrote op fixtures")
 
 
+
+# ------------------------------------------------------------------ fixtures on the reference's bundled example images
+IMG_ROOT = "/root/reference/datasets"
+
+
+def gen_real_images_fixture():
+    """The example images the reference ships for its own test configs (datasets/example_general_4X, example_face_8X;
+    test_SR_DF2K_4X_HCFlow.yml:13-22, test_SR_CelebA_8X_HCFlow.yml:13-22) as uint8 RGB arrays: DATA the GPU box needs as
+    inputs (the reference tree does not travel)."""
+    from PIL import Image
+
+    def rd(path):
+        return np.asarray(Image.open(path).convert("RGB"), dtype=np.uint8)
+    out = {"butterfly_lr": rd(IMG_ROOT + "/example_general_4X/LR/butterfly.png"),
+           "butterfly_hr": rd(IMG_ROOT + "/example_general_4X/HR/butterfly.png")}
+    names = sorted(os.listdir(IMG_ROOT + "/example_face_8X/LR"), key=lambda n: int(os.path.splitext(n)[0]))
+    out["face_names"] = np.array(names)
+    out["face_lr"] = np.stack([rd(IMG_ROOT + "/example_face_8X/LR/" + n) for n in names])
+    out["face_hr"] = np.stack([rd(IMG_ROOT + "/example_face_8X/HR/" + n) for n in names])
+    path = os.path.join(HERE, "real_images.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), {k: v.shape for k, v in out.items()})
+
+
+def img_tensor(a):
+    """uint8 [.., H, W, 3] RGB -> float [B, 3, H, W] in [0, 1]: what the LQGT dataset hands to feed_data
+    (data/LQGT_dataset.py: BGR->RGB, HWC->CHW, /255)."""
+    a = np.asarray(a)
+    if a.ndim == 3:
+        a = a[None]
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 3, 1, 2))).float() / 255.
+
+
+def pack_out(out, key, x, stride=3):
+    """Large outputs are stored as a stride-3 subsample (exact values; 3 is coprime to every tile size, so all tile phases are hit) + a float64 digest of the whole tensor
+    (n, sum, sum of squares, seeded random projection): tests/util.py::check_packed."""
+    x = np.asarray(np_(x) if torch.is_tensor(x) else x)
+    out[key + "_sub"] = np.ascontiguousarray(x[..., 1::stride, 2::stride])
+    f = x.astype(np.float64).reshape(-1)
+    r = np.random.RandomState(12345).standard_normal(f.size)
+    out[key + "_dig"] = np.array([f.size, f.sum(), (f * f).sum(), (f * r).sum()], dtype=np.float64)
+    out[key + "_shape"] = np.array(x.shape, dtype=np.int64)
+
+
+def seeded_eps(cfg, B, h, w, tau, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g) * tau for s in eps_shapes(cfg, B, h, w)]
+
+
+def gen_real_net_fixture(name, preset_name, ref_sr, ref_rs, lr, hr, seed, taus=(0.0, 0.8), fit_actnorm=True, images=""):
+    """Full-depth shipped configuration on real images (or a ragged multi-tile random LR): the seeded recipe, optionally with
+    every ActNorm re-fitted by the REFERENCE's own data-dependent initialisation on this very HR / LR pair (ActNorms.py:29-43;
+    the activations are then unit-variance per channel, the regime of a trained net), then inverse passes with seeded eps
+    (replayed into the reference) and the NLL. eps / noise are regenerated from their seeds on the GPU box."""
+    cfg = preset(preset_name)
+    net, params = build(ref_sr if cfg.sr else ref_rs, cfg, seed)
+    B, _, h, w = lr.shape
+    out = {"preset": preset_name, "seed": seed, "images": images, "B": B, "h": h, "w": w}
+    if not images:          # seeded random inputs: regenerated on the GPU box (tests/util.py::real_inputs)
+        gi = torch.Generator().manual_seed(seed + 500)
+        lr = torch.rand(lr.shape, generator=gi)
+        hr = torch.rand(hr.shape, generator=gi)
+        out["input_seed"] = seed + 500
+    dg = param_digest(params)
+    out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
+    an = [(k, m) for k, m in net.named_modules() if "ActNorm" in type(m).__name__]
+    noise_seed = seed + 1000
+    with torch.no_grad():
+        if fit_actnorm:
+            for _, m in an:
+                m.bias.data.zero_()
+                m.logs.data.zero_()
+                m.inited = False
+            net.train()
+            noise0 = torch.rand(hr.shape, generator=torch.Generator().manual_seed(noise_seed))
+            with Capture(replay_rand=[noise0]):
+                if cfg.sr:
+                    net(hr=hr, lr=lr, reverse=False)
+                else:
+                    net(hr=hr, reverse=False)
+            assert all(m.inited for _, m in an)
+            net.eval()
+            out["an_keys"] = np.array([k for k, _ in an])
+            for i, (k, m) in enumerate(an):
+                out["an_bias_%d" % i] = np_(m.bias).reshape(-1)
+                out["an_logs_%d" % i] = np_(m.logs).reshape(-1)
+            print("  %s: %d ActNorms fitted by the reference, logs range [%.3f, %.3f]" % (
+                name, len(an), min(float(m.logs.min()) for _, m in an), max(float(m.logs.max()) for _, m in an)))
+        out["fit_actnorm"] = bool(fit_actnorm)
+        out["noise_seed"] = noise_seed
+        for ti, tau in enumerate(taus):
+            es = seed + 2000 + ti
+            eps = seeded_eps(cfg, B, h, w, tau, es)
+            with Capture(replay_normal=[e.clone() for e in eps]) as cap:
+                y_raw = net.flow(z=lr, eps_std=tau, reverse=True)
+            if tau > 0:
+                assert len(cap.normal) == len(eps)
+            out["inv%d_tau" % ti] = np.float64(tau)
+            out["inv%d_eps_seed" % ti] = es
+            pack_out(out, "inv%d_raw" % ti, y_raw)
+            frac = float(((y_raw < 0) | (y_raw > 1)).float().mean())
+            print("  %s tau=%.1f raw range [%.3f, %.3f] clamped frac %.3f" % (name, tau, float(y_raw.min()), float(y_raw.max()), frac))
+            assert torch.isfinite(y_raw).all()
+        noise = torch.rand(hr.shape, generator=torch.Generator().manual_seed(noise_seed))
+        if cfg.sr:
+            with Capture(replay_rand=[noise]):
+                lr_hat, nll = net(hr=hr, lr=lr, reverse=False)
+            with Capture(replay_rand=[noise]):
+                _, nll_self = net(hr=hr, lr=lr_hat, reverse=False)
+            out.update(fwd_nll=np.float64(float(nll)), fwd_nll_self=np.float64(float(nll_self)), fwd_lr=np_(lr_hat))
+            print("  %s nll %.6f nll_self %.6f" % (name, float(nll), float(nll_self)))
+        else:
+            lr_hat, z1, z2 = net(hr=hr, reverse=False)
+            out["fwd_lr"] = np_(lr_hat)
+            pack_out(out, "fwd_z1", z1)
+            pack_out(out, "fwd_z2", z2)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def gen_checkpoint_fixture(name, preset_name, ref_sr, ref_rs, seed):
+    """Checkpoint fidelity, both directions (base_model.py:79-120). (1) reference -> ours: the REFERENCE module wrapped in
+    nn.DataParallel (HCFlow_SR_model.py:33-36) is initialised by the reference's own constructors (+ small seeded values for
+    the zero-initialised tensors so that it computes something), its `state_dict()` -- 'module.'-prefixed keys -- is what
+    torch.save would write; stored here as arrays in state-dict order together with one reference output. (2) ours ->
+    reference: the state dict in the fixture IS checked to load strictly into our class (tests) and `build()` already loads our
+    tensors into the reference strictly."""
+    cfg = preset(preset_name)
+    ref_cls = ref_sr if cfg.sr else ref_rs
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    net = ref_cls(opt=cfg.to_opt(), step=0)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if "haar_weights" in k:
+                continue
+            if float(v.abs().max()) == 0.0:                      # ActNorm bias / logs, Conv2dZeros: zero in a fresh reference net
+                v.copy_(torch.randn(v.shape, generator=g) * 0.02)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net.eval()
+    wrapped = torch.nn.DataParallel(net)
+    sd = wrapped.state_dict()
+    keys = list(sd.keys())
+    assert all(k.startswith("module.") for k in keys)
+    assert [k[7:] for k in keys] == [k for k, _, _ in param_spec(cfg)]
+    out = {"preset": preset_name, "keys": np.array(keys)}
+    for i, k in enumerate(keys):
+        out["t_%d" % i] = np_(sd[k])
+    B, h, w = 2, 10, 12
+    lr = torch.rand(B, 3, h, w, generator=g)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=g)
+    eps = seeded_eps(cfg, B, h, w, 0.8, seed + 5)
+    with torch.no_grad():
+        with Capture(replay_normal=[e.clone() for e in eps]):
+            y = net(lr=lr, eps_std=0.8, reverse=True)
+        out.update(lr=np_(lr), hr=np_(hr), eps_seed=seed + 5, inv_out=np_(y))
+        if cfg.sr:
+            noise = torch.rand(hr.shape, generator=g)
+            with Capture(replay_rand=[noise]):
+                lr_hat, nll = net(hr=hr, lr=lr, reverse=False)
+            out.update(fwd_noise=np_(noise), fwd_nll=np.float64(float(nll)))
+        else:
+            lr_hat, z1, z2 = net(hr=hr, reverse=False)
+            out.update(fwd_lr=np_(lr_hat))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     torch.set_num_threads(8)
     ref_sr, ref_rs = import_reference()
     only = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if only in ("all", "real"):
+        gen_real_images_fixture()
+        im = np.load(os.path.join(HERE, "real_images.npz"))
+        # full depth, ragged multi-tile LR (24 x 72 -> 3 x 3 conv tiles of 8 x 32 at level 1, ragged last tile)
+        gen_real_net_fixture("net_sr4_full_ragged", "SR_DF2K_4X", ref_sr, ref_rs, torch.empty(1, 3, 24, 72),
+                             torch.empty(1, 3, 96, 288), seed=71, fit_actnorm=False)
+        gen_real_net_fixture("net_rescale_full_ragged", "Rescaling_DF2K_4X", ref_sr, ref_rs, torch.empty(1, 3, 24, 72),
+                             torch.empty(1, 3, 96, 288), seed=72, taus=(0.0, 1.0), fit_actnorm=False)
+        # the reference's own example images, ActNorms fitted by the reference's data-dependent init on them
+        gen_real_net_fixture("net_sr4_real", "SR_DF2K_4X", ref_sr, ref_rs, img_tensor(im["butterfly_lr"]),
+                             img_tensor(im["butterfly_hr"]), seed=73, images="butterfly")
+        gen_real_net_fixture("net_sr8_real", "SR_CelebA_8X", ref_sr, ref_rs, img_tensor(im["face_lr"]),
+                             img_tensor(im["face_hr"]), seed=74, images="face")
+        gen_real_net_fixture("net_rescale_real", "Rescaling_DF2K_4X", ref_sr, ref_rs, img_tensor(im["butterfly_lr"]),
+                             img_tensor(im["butterfly_hr"]), seed=75, taus=(0.0, 1.0), images="butterfly")
+        if only == "real":
+            return
+    if only in ("all", "ckpt"):
+        gen_checkpoint_fixture("ckpt_sr4_micro", "SR_4X_micro", ref_sr, ref_rs, seed=81)
+        gen_checkpoint_fixture("ckpt_rescale_micro", "Rescaling_4X_micro", ref_sr, ref_rs, seed=82)
+        if only == "ckpt":
+            return
     if only in ("all", "metrics"):
         gen_metrics_fixture()
         if only == "metrics":

@@ -78,3 +78,31 @@ def test_frozen_haar_weights_survive_the_round_trip(tmp_path):
     _load_network(path, net2)
     for (k, a), (_, b) in zip(haar, [(k, v) for k, v in net2.named_parameters() if k.endswith("haar_weights")]):
         assert torch.equal(a, b) and set(a.unique().tolist()) == {-1.0, 1.0}
+
+
+@pytest.mark.parametrize("name", ["ckpt_sr4_micro", "ckpt_rescale_micro"])
+def test_reference_written_checkpoint_loads_strictly_on_cpu(name, tmp_path):
+    """The fixture holds the state dict of the REFERENCE module under nn.DataParallel ('module.' keys,
+    tests/golden/make_golden.py::gen_checkpoint_fixture): written with torch.save and read back through load_network's
+    prefix stripping into our class with strict=True; the CPU oracle reproduces the reference output stored beside it."""
+    import collections as C
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    from oracle import hcflow_oracle as O
+    from tests.util import load_golden, t, maxdiff, seeded_eps
+    g = load_golden(name)
+    cfg = preset(str(g["preset"]))
+    sd = C.OrderedDict((str(k), t(g["t_%d" % i])) for i, k in enumerate(g["keys"]))
+    path = os.path.join(tmp_path, "ref_G.pth")
+    torch.save(sd, path)
+    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    _load_network(path, torch.nn.DataParallel(net), strict=True)
+    want = [(k, tuple(s)) for k, s, _ in param_spec(cfg)]
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == want
+    p = {k: v.clone() for k, v in net.state_dict().items()}
+    lr = t(g["lr"])
+    B, _, h, w = lr.shape
+    with torch.no_grad():
+        eps = seeded_eps(cfg, B, h, w, 0.8, int(g["eps_seed"]))
+        out = (O.sr_inverse if cfg.sr else O.rescale_inverse)(lr, p, cfg, 0.8, eps)
+    assert maxdiff(out, g["inv_out"]) <= 1e-5

@@ -277,3 +277,65 @@ def test_rescaling_step_gradients_match_reference():
     (l_lr + l_z + l_hr).backward()
     grads = [np.zeros(tuple(q[k].shape), np.float32) if q[k].grad is None else q[k].grad.numpy() for k, _, _ in param_spec(cfg)]
     check_grads_against_fixture(g, grads, rtol=5e-4)
+
+
+# ---------------------------------------------------------------- full depth, multi-tile sizes, real images (round 3)
+REAL = ["net_sr4_full_ragged", "net_rescale_full_ragged", "net_sr4_real", "net_sr8_real", "net_rescale_real"]
+
+
+@pytest.mark.parametrize("name", REAL)
+def test_oracle_full_depth_on_real_images_and_ragged_sizes(name):
+    """Full-depth shipped nets at multi-tile LR sizes: the reference's bundled example images with ActNorms fitted by the
+    reference's own data-dependent init (net_*_real) and a ragged 24 x 72 LR (net_*_ragged); outputs are pinned through a
+    stride-3 subsample + whole-tensor digest (make_golden.pack_out)."""
+    from tests.util import real_inputs, real_params, seeded_eps, check_packed
+    g = load_golden(name)
+    cfg, p = real_params(g)
+    lr, hr = real_inputs(g)
+    B, _, h, w = lr.shape
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        for ti in (0, 1):
+            tau = float(g["inv%d_tau" % ti])
+            eps = seeded_eps(cfg, B, h, w, tau, int(g["inv%d_eps_seed" % ti]))
+            fn = O.sr_inverse if cfg.sr else O.rescale_inverse
+            raw = fn(lr, p, cfg, tau, eps, clamp=False)
+            scale = max(1.0, float(np.abs(g["inv%d_raw_sub" % ti]).max()))
+            check_packed(g, "inv%d_raw" % ti, raw, 2e-5 * scale)
+        if cfg.sr:
+            noise = torch.rand(hr.shape, generator=torch.Generator().manual_seed(int(g["noise_seed"])))
+            lr_hat, nll = O.sr_forward(hr, lr, p, cfg, noise=noise)
+            assert abs(float(nll) - float(g["fwd_nll"])) <= 1e-5 * abs(float(g["fwd_nll"]))
+            _, nll_self = O.sr_forward(hr, t(g["fwd_lr"]), p, cfg, noise=noise)
+            assert abs(float(nll_self) - float(g["fwd_nll_self"])) <= 1e-4
+            d = (lr_hat - t(g["fwd_lr"])).abs()
+            assert float(d.max()) <= 1.0 / 255 + 1e-6 and float((d > 1e-6).float().mean()) < 0.01
+        else:
+            lr_hat, z1, z2 = O.rescale_forward(hr, p, cfg)
+            assert maxdiff(lr_hat, g["fwd_lr"]) <= 1e-5
+            check_packed(g, "fwd_z1", z1, 2e-5 * max(1.0, float(np.abs(g["fwd_z1_sub"]).max())))
+            check_packed(g, "fwd_z2", z2, 2e-5 * max(1.0, float(np.abs(g["fwd_z2_sub"]).max())))
+
+
+@pytest.mark.parametrize("name", ["net_sr4_real", "net_sr8_real", "net_rescale_real"])
+def test_oracle_actnorm_data_init_on_real_images(name):
+    """The oracle's data-dependent ActNorm init on the reference's example images reproduces what the reference fitted."""
+    from tests.util import real_inputs, params_for
+    g = load_golden(name)
+    cfg, p = params_for(g)
+    lr, hr = real_inputs(g)
+    keys = [str(k) for k in g["an_keys"]]
+    ip = O.InitParams(p, keys)
+    for k in keys:
+        ip[k + ".bias"] = torch.zeros_like(p[k + ".bias"])
+        ip[k + ".logs"] = torch.zeros_like(p[k + ".logs"])
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        noise = torch.rand(hr.shape, generator=torch.Generator().manual_seed(int(g["noise_seed"])))
+        if cfg.sr:
+            O.sr_forward(hr, lr, ip, cfg, noise=noise)
+        else:
+            O.rescale_forward(hr, ip, cfg)
+    for i, k in enumerate(keys):
+        assert maxdiff(ip[k + ".bias"].reshape(-1), g["an_bias_%d" % i]) <= 2e-4, (k, "bias")
+        assert maxdiff(ip[k + ".logs"].reshape(-1), g["an_logs_%d" % i]) <= 2e-4, (k, "logs")

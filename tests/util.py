@@ -39,3 +39,62 @@ def maxdiff(a, b):
     a = a.detach().cpu().double() if torch.is_tensor(a) else torch.from_numpy(np.asarray(a)).double()
     b = b.detach().cpu().double() if torch.is_tensor(b) else torch.from_numpy(np.asarray(b)).double()
     return float((a - b).abs().max())
+
+
+# ---------------------------------------------------------------- fixtures on real images / seeded large inputs
+def real_inputs(g):
+    """(lr, hr) float tensors of a net_*_real / *_ragged fixture: the reference's bundled example images
+    (tests/golden/real_images.npz) or seeded random inputs regenerated from ``input_seed``."""
+    name = str(g["images"])
+    if name:
+        im = load_golden("real_images")
+        key = {"butterfly": "butterfly", "face": "face"}[name]
+
+        def cv(a):
+            a = a[None] if a.ndim == 3 else a
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 3, 1, 2))).float() / 255.
+        return cv(im[key + "_lr"]), cv(im[key + "_hr"])
+    cfg = preset(str(g["preset"]))
+    B, h, w = int(g["B"]), int(g["h"]), int(g["w"])
+    gi = torch.Generator().manual_seed(int(g["input_seed"]))
+    lr = torch.rand(B, 3, h, w, generator=gi)
+    hr = torch.rand(B, 3, h * cfg.scale, w * cfg.scale, generator=gi)
+    return lr, hr
+
+
+def real_params(g):
+    """The fixture's weights: the seeded recipe, with every ActNorm replaced by the values the REFERENCE fitted on the
+    fixture's images (data-dependent initialisation) when the fixture holds them."""
+    cfg, p = params_for(g)
+    if "an_keys" in g.files:
+        p = dict(p)
+        for i, k in enumerate(g["an_keys"]):
+            k = str(k)
+            p[k + ".bias"] = t(g["an_bias_%d" % i]).reshape(p[k + ".bias"].shape).clone()
+            p[k + ".logs"] = t(g["an_logs_%d" % i]).reshape(p[k + ".logs"].shape).clone()
+    return cfg, p
+
+
+def seeded_eps(cfg, B, h, w, tau, seed):
+    from hcflow_amd.config import eps_shapes
+    g = torch.Generator().manual_seed(int(seed))
+    return [torch.randn(s, generator=g) * tau for s in eps_shapes(cfg, B, h, w)]
+
+
+def check_packed(g, key, x, tol):
+    """``x`` against a fixture entry stored by make_golden.pack_out: stride-3 subsample (exact values, every tile phase) and a
+    float64 digest of the whole tensor. Returns the max deviation on the subsample."""
+    x = x.detach().cpu().double().numpy() if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
+    assert tuple(x.shape) == tuple(int(v) for v in g[key + "_shape"]), (x.shape, g[key + "_shape"])
+    sub = x[..., 1::3, 2::3]
+    d = float(np.abs(sub - g[key + "_sub"].astype(np.float64)).max())
+    assert d <= tol, (key, d, tol)
+    n, s1, s2, pr = [float(v) for v in g[key + "_dig"]]
+    f = x.reshape(-1)
+    assert f.size == int(n)
+    r = np.random.RandomState(12345).standard_normal(f.size)
+    amax = max(1.0, float(np.abs(f).max()))
+    assert abs(f.sum() - s1) <= tol * n, (key, "sum", f.sum(), s1)
+    assert abs((f * f).sum() - s2) <= 2 * tol * amax * n, (key, "sumsq")
+    assert abs((f * r).sum() - pr) <= 6 * tol * np.sqrt(n), (key, "projection", (f * r).sum(), pr)
+    return d
