@@ -98,3 +98,39 @@ def check_packed(g, key, x, tol):
     assert abs((f * f).sum() - s2) <= 2 * tol * amax * n, (key, "sumsq")
     assert abs((f * r).sum() - pr) <= 6 * tol * np.sqrt(n), (key, "projection", (f * r).sum(), pr)
     return d
+
+
+# ---------------------------------------------------------------- recorded reference-caller runs (tests/golden/callers_*.npz)
+def caller_cfg(g, tag):
+    from hcflow_amd.config import NetConfig  # noqa: F401  (eval below)
+    return eval(str(g[tag + "_preset_opt"][0]))
+
+
+def caller_calls(g, tag):
+    """[(class name, training mode, grad enabled, {kwarg: value | ('T', shape)})] as the reference's callers issued them."""
+    out = []
+    for row in g[tag + "_calls"]:
+        cls, tr, gr, refusal, kws = str(row).split("|", 4)
+        kw = {}
+        import re
+        for k, v in re.findall(r"(\w+)=(T\[[^\]]*\]|[^,]+)", kws):
+            kw[k] = ("T", tuple(eval(v[1:]))) if v.startswith("T[") else eval(v)
+        out.append((cls, tr.endswith("1"), gr.endswith("1"), refusal, kw))
+    return out
+
+
+def regen_draws(g, tag, seed=0):
+    """The torch.rand / torch.normal draws the reference made (global CPU generator after torch.manual_seed(seed),
+    test_HCFlow.py:34), regenerated by the same calls in the same order and checked against the recorded digests."""
+    torch.manual_seed(seed)
+    out = []
+    for row, dig in zip(g[tag + "_draws"], g[tag + "_draw_digest"]):
+        kind, shape, std = str(row).split("|")
+        shape = tuple(int(v) for v in shape.split(","))
+        if kind == "rand":
+            e = torch.rand(shape)
+        else:
+            e = torch.normal(mean=torch.zeros(shape), std=torch.ones(shape) * float(std))
+        assert abs(float(e.double().sum()) - dig[0]) <= 1e-6 * max(1.0, abs(dig[0])), "torch CPU generator stream differs from the recording"
+        out.append((kind, e))
+    return out

@@ -10,6 +10,7 @@ tool runs the engine's range probe (hcf_debug_range_probe: a max-reduction besid
   (b) the seeded weight recipe (hcflow_amd/params.py) with every conv weight scaled x1 / x2 / x4 / x8 on BASELINE config 2's LR
       size, to show where the guard starts to fire,
 and reports per net the largest values, the layers that hold them and the headroom factor 65504 / max."""
+import contextlib
 import json
 import os
 import sys
@@ -27,7 +28,8 @@ F16_MAX = 65504.0
 
 
 def module(cfg, p):
-    net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+    with contextlib.redirect_stdout(sys.stderr):         # the constructor prints the reference's `shapes:` line
+        net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
     net.load_state_dict(p, strict=True)
     for m in net.modules():
         if "ActNorm" in type(m).__name__:
