@@ -82,6 +82,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling, preset, make_params
+    from hcflow_amd.dist import gathered_step, timed_region
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -127,10 +128,10 @@ def main():
                 lrq = fixed_lrq
             last["lrq"] = lrq
             out = net(lr=lrq, **kw)
+            if world > 1:
+                dist.all_gather_into_tensor(out_all, out)     # RCCL over xGMI: output batch only
         else:
-            out = net(lr=lr, **kw)
-        if world > 1:
-            dist.all_gather_into_tensor(out_all, out)     # RCCL over xGMI: output batch only
+            out = gathered_step(net, lr, args.tau, 4242 + it, out_all)   # sample this rank's shard + RCCL all-gather (N > 1)
         return out
 
     def timed(mode, warmup, steps):
@@ -141,22 +142,15 @@ def main():
             for i in range(warmup):
                 step(i)
             eng.profile_convs(True)
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                out = step(warmup + i)
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            keep = {}
+
+            def one(i):
+                keep["out"] = step(i)
+            # barrier + synchronize | exactly `steps` steps | barrier + synchronize, MAX over ranks (hcflow_amd/dist.py)
+            dt = timed_region(one, steps, first=warmup)
             eng.profile_convs(False)
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        assert bool(torch.isfinite(out).all())
-        return float(tmax.item()), roofline_block(eng, mode, steps, float(tmax.item()))
+        assert bool(torch.isfinite(keep["out"]).all())
+        return dt, roofline_block(eng, mode, steps, dt)
 
     def roofline_block(eng, mode, steps, dt):
         variants = []

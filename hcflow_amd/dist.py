@@ -94,3 +94,42 @@ def sharded_rescale_roundtrip(net, hr: torch.Tensor, eps_std: float = 1.0, group
         lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.      # Basic.Quant.forward (Basic.py:187-191)
         return net(lr=lrq, z=None, u=None, eps_std=eps_std, reverse=True)
     return sharded_apply(fn, hr, group)
+
+
+# ---------------------------------------------------------------- the benchmark's N-GPU step (bench.py --gpus N)
+def gathered_step(net, lr: torch.Tensor, tau: float, seed: int, out_all: Optional[torch.Tensor] = None, group=None, **kw):
+    """One bench step on this rank: sample THIS rank's shard (its LR batch; eps of global samples [rank B, (rank + 1) B) of the
+    job-wide seed, hcf_inverse_ex) and, for N > 1, all-gather the output batch into ``out_all`` -- the only collective of the
+    path (RCCL over xGMI with backend "nccl"). Weak scaling: per-rank work is fixed."""
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    out = net(lr=lr, z=None, u=None, eps_std=tau, reverse=True, seed=seed, sample_offset=rank * lr.shape[0], **kw)
+    if out_all is not None and on and dist.get_world_size(group) > 1:
+        dist.all_gather_into_tensor(out_all, out.contiguous(), group=group)
+    return out
+
+
+def timed_region(step_fn: Callable[[int], object], steps: int, first: int = 0, group=None) -> float:
+    """bench.py's timing contract: barrier + device synchronize, EXACTLY ``steps`` calls of ``step_fn(i)``, barrier +
+    synchronize, wall time, MAX over ranks. Returns seconds (the same value on every rank)."""
+    import time
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    cuda = torch.cuda.is_available()
+    if on:
+        dist.barrier(group=group)
+    if cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(first + i)
+    if on:
+        dist.barrier(group=group)
+    if cuda:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if on:
+        gpu = cuda and dist.get_backend(group) == "nccl"
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if gpu else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+        dt = float(tmax.item())
+    return dt

@@ -130,3 +130,71 @@ def test_actnorm_init_is_broadcast_from_rank0_world2():
     for p_ in procs:
         p_.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _rt_worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from oracle import hcflow_oracle as O
+        from hcflow_amd.config import preset
+        from hcflow_amd.params import make_params
+        from hcflow_amd.dist import sharded_rescale_roundtrip, gathered_step, timed_region, shard_bounds as sb
+        cfg = preset("Rescaling_4X_tiny")
+        p = make_params(cfg, 13)
+        hr = torch.rand(B, 3, 16, 24, generator=torch.Generator().manual_seed(1))
+
+        class Net:      # the rescaling class's call surface (forward -> (LR^, z1, z2); reverse -> HR), oracle underneath
+            def __call__(self, hr=None, lr=None, z=None, u=None, eps_std=None, reverse=False):
+                with torch.no_grad():
+                    return O.rescale_inverse(lr, p, cfg, eps_std) if reverse else O.rescale_forward(hr, p, cfg)
+
+        out = sharded_rescale_roundtrip(Net(), hr, eps_std=0.0)          # tau 0: deterministic decode
+        with torch.no_grad():
+            lr_hat, _, _ = O.rescale_forward(hr, p, cfg)
+            ref = O.rescale_inverse((lr_hat.clamp(0, 1) * 255.).round() / 255., p, cfg, 0.0)
+        ok = out.shape == ref.shape and float((out - ref).abs().max()) <= 1e-5
+        # bench.py's N > 1 step: each rank samples ITS batch with the job seed and its global sample offset, ONE all-gather
+        seen = []
+
+        class Stub:
+            def __call__(self, lr=None, z=None, u=None, eps_std=None, reverse=False, seed=None, sample_offset=0):
+                seen.append((int(seed), int(sample_offset)))
+                return lr.repeat_interleave(4, 2).repeat_interleave(4, 3) + float(seed)
+
+        mine = torch.full((B, 3, 2, 2), float(rank))
+        out_all = torch.empty(world * B, 3, 8, 8)
+
+        def step(i):
+            time.sleep(0.02 * (rank + 1))                                # rank 1 is the slow one
+            gathered_step(Stub(), mine, 0.8, 4242 + i, out_all)
+
+        dt = timed_region(step, 3, first=5)
+        ok = ok and seen == [(4242 + 5 + i, rank * B) for i in range(3)]
+        want = torch.cat([torch.full((B, 3, 8, 8), float(r) + 4242 + 7) for r in range(world)], 0)
+        ok = ok and torch.equal(out_all, want)
+        ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64))
+        ok = ok and float(ts[0]) == float(ts[1]) and dt >= 3 * 0.02 * world          # MAX over ranks, same on every rank
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [2, 3])
+def test_sharded_rescale_roundtrip_and_bench_step_gloo_world2(B):
+    """Config 4's multi-GPU leg (forward -> Quant -> inverse per shard, all-gather of the HR batch only) and the factored
+    bench step / timing contract (hcflow_amd/dist.py: gathered_step, timed_region) on two gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rt_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p_ in procs:
+        p_.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
