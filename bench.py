@@ -15,8 +15,8 @@ rank samples its own shard (weak scaling, no data-path collective besides the ou
 `value`, `ms_per_step` and `roofline` belong to the MODULE'S DEFAULT conv numerics (f16x3: fp32-equivalent split products
 on the f16 matrix cores, hcflow_amd/arch.py); `other_precision` repeats the same timed region (same K steps) on the exact
 fp32-MFMA kernels with its own roofline block, and `precision.check` gives the deviation between the two on the same draws.
-The module runs with the "lazy" range-check policy here: no call inside the timed region waits for the device; the
-asynchronous f16x3 range flag is read once after the loops (`range_overflow_in_any_pass`).
+The module runs with ITS DEFAULT range-check policy ("sync": every call reads the f16x3 range flag before it returns and would
+re-run an overflowed pass exactly; `precision.range_check` names the policy that was timed; --range-check lazy defers the check).
 
 The JSON line also carries
   roofline      dominant kernel = the conv instantiation with the LARGEST TOTAL TIME in the timed region (named as rocprofv3
@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "exact"],
                     help="headline conv numerics: f16x3 = the module default (fp32-equivalent split products on f16 MFMA); "
                          "exact = fp32 MFMA. The other mode is timed over the same number of steps and reported beside it")
+    ap.add_argument("--range-check", default="default", choices=["default", "sync", "lazy", "off"],
+                    help="f16x3 range-check policy (default: the module's own default, i.e. what an unmodified test_HCFlow.py gets)")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the timed run of the other precision")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the f16x3-vs-exact deviation check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,7 +113,8 @@ def main():
     g = torch.Generator().manual_seed(1000 + rank)
     lr = torch.rand(B, 3, h, h, generator=g).to(dev)
     out_all = torch.empty(world * B, 3, h * cfg.scale, h * cfg.scale, device=dev) if world > 1 else None
-    net.set_range_check("lazy")      # nothing inside the timed region waits for the device; the flag is read once at the end
+    if args.range_check != "default":     # the headline runs the MODULE DEFAULT ("sync": every call checks the f16x3 range flag and
+        net.set_range_check(args.range_check)   # would re-run exactly before returning); "lazy" defers the check to the end of the run
 
     roundtrip = not cfg.sr          # config 4: rescaling forward -> Quant -> inverse (HCFlow_Rescaling_model.py:306-324)
     hr_in = torch.rand(B, 3, h * cfg.scale, h * cfg.scale, generator=g).to(dev) if roundtrip else None

@@ -413,6 +413,7 @@ class _EngineModule(nn.Module):
         """Force a repack of every engine on its next call. Needed after writes the version counters do not see
         (``p.data.copy_()`` / ``p.data.mul_()`` as EMA or clipping code does): the engine otherwise keeps its packed
         weights, inverse matrices and log-det constants. Also re-arms the "ActNorm already fitted" bookkeeping."""
+        self.__dict__.pop("_slots", None)             # re-resolve the parameter slots (a sub-module may have been replaced)
         for ent in self._engines.values():
             ent["stamp"] = None
             ent["ptrs"] = None
@@ -425,18 +426,34 @@ class _EngineModule(nn.Module):
     def _tensors(self):
         """[(key, tensor)] in state_dict order, resolved through the ATTRIBUTE tree: nn.DataParallel replicas carry their
         parameters as plain tensor attributes (torch >= 1.5: replica.parameters() is empty), and those tensors are the
-        ones autograd must see so that gradients flow back to the wrapped module (HCFlow_SR_model.py:33-36)."""
+        ones autograd must see so that gradients flow back to the wrapped module (HCFlow_SR_model.py:33-36).
+        The (owner module, attribute) pairs are resolved once per module OBJECT (walking 1 500-1 900 dotted paths costs
+        ~10 ms of Python per call, several times per forward); a replica is a different object and resolves its own."""
+        slots = self._slots_for_self()
         out = []
+        for key, (obj, name) in zip(self._spec_keys, slots):
+            t = obj._parameters.get(name)
+            out.append((key, t if t is not None else getattr(obj, name)))
+        return out
+
+    def _slots_for_self(self):
+        cached = self.__dict__.get("_slots")
+        if cached is not None and cached[0] == id(self):
+            return cached[1]
+        slots = []
         for key in self._spec_keys:
             obj = self
             path = key.split(".")
             for a in path[:-1]:
                 obj = getattr(obj, a)
-            out.append((key, getattr(obj, path[-1])))
-        return out
+            slots.append((obj, path[-1]))
+        object.__setattr__(self, "_slots", (id(self), slots))
+        return slots
 
     def _device(self):
-        return self._tensors()[0][1].device
+        obj, name = self._slots_for_self()[0]
+        t = obj._parameters.get(name)
+        return (t if t is not None else getattr(obj, name)).device
 
     def set_precision(self, mode: str):
         """"exact": fp32 MFMA convolutions (default). "f16x3": fp32-equivalent split products on the
