@@ -79,6 +79,9 @@ enum { PREC_EXACT = 0, PREC_F16X3 = 1 };
 int launch_conv(const ConvArgs& a, int taps, hipStream_t st);
 // fp32-equivalent conv on f16 MFMA (3-term split, hcf_conv_f16x3.hip); wpack = f16x3 pack
 int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
+// FCN conv1 (3x3, <= 16 input channels = one K chunk) + conv2 (1x1 64 -> 64) as one persistent launch with resident weights
+// (hcf_conv_fcn.hip); a.res1 = optional pre-activation term of conv1 (64 channels). HCF_ERR_UNSUPPORTED: use the generic kernel
+int launch_fcn12(const ConvArgs& a, hipStream_t st);
 // Winograd F(2x2,3x3) form of the same f16x3 conv (hcf_conv_wino.hip): eligible layers only (pack size 0 otherwise);
 // HCF_ERR_UNSUPPORTED when the call cannot take it (upsampled source, unaligned views, > 2^24 pixels): use the direct kernel
 size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out);

@@ -400,9 +400,12 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
           float v = (acc[m][r] * UNSPLIT + bias1) * scale1;
           v = apply_act(v, slope1);
           const _Float16 h = (_Float16)v;
-          char* rec = lds + (px * 4 + kc) * 64 + kpos * 2;
-          *reinterpret_cast<_Float16*>(rec) = h;
-          *reinterpret_cast<_Float16*>(rec + 32) = (_Float16)(v - (float)h);
+          // 16-byte slot (kc, plane, k-half) of the pixel's 256-byte record, XOR-swizzled with the pixel index: the A-fragment
+          // reads below take the SAME slot of 32 consecutive pixels (256 bytes apart = the same four banks); with the swizzle a
+          // group of 16 lanes touches 16 distinct slots (conflict-free ds_read_b128) instead of one
+          const int sw = px & 15, kh = kpos >> 3, kb = (kpos & 7) * 2;
+          *reinterpret_cast<_Float16*>(lds + px * 256 + (((kc * 4 + kh) ^ sw) << 4) + kb) = h;
+          *reinterpret_cast<_Float16*>(lds + px * 256 + (((kc * 4 + 2 + kh) ^ sw) << 4) + kb) = (_Float16)(v - (float)h);
         }
       __syncthreads();
     }
@@ -419,9 +422,9 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       f16x8 ahi[MT], alo[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const char* rec = lds + (((MT * wm + m) * TW + li) * 4 + kc) * 64 + half * 16;
-        ahi[m] = *reinterpret_cast<const f16x8*>(rec);
-        alo[m] = *reinterpret_cast<const f16x8*>(rec + 32);
+        const char* rec = lds + ((MT * wm + m) * TW + li) * 256;
+        ahi[m] = *reinterpret_cast<const f16x8*>(rec + (((kc * 4 + half) ^ (li & 15)) << 4));
+        alo[m] = *reinterpret_cast<const f16x8*>(rec + (((kc * 4 + 2 + half) ^ (li & 15)) << 4));
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[m], b1, acc[m], 0, 0, 0);

@@ -633,7 +633,13 @@ struct hcf_engine {
         a.tz = tail->z; a.tzo = tail->out; a.tmat = tail->mat; a.tbias = tail->an_bias; a.tmul = tail->an_mul;
         a.tC = tail->C; a.tns = tail->ns; a.tmode = tail->mode;
       }
-      r = launch_conv_f16x3(a, cv.taps, st);
+      r = HCF_ERR_UNSUPPORTED;
+      if (fuse2 && !tail) {                 // one K chunk: the persistent small-K form (res1 = pre-activation term, if any)
+        r = launch_fcn12(a, st);
+        if (r == HCF_OK && prof) prof_events[prof_used].kind = 5;
+        if (r == HCF_ERR_UNSUPPORTED && res1.p) { fail(HCF_ERR_STATE, "internal: pre-activation term without the fcn12 kernel"); return; }
+      }
+      if (r == HCF_ERR_UNSUPPORTED) r = launch_conv_f16x3(a, cv.taps, st);
     } else {
       r = launch_conv(a, cv.taps, st);
     }
