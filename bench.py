@@ -316,6 +316,7 @@ def cpu_baseline(cfg, params, h, passes):
             out = fn(lr, params, cfg, 0.0)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
+    c_port = c_port_sample()
     cpu_model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -328,7 +329,43 @@ def cpu_baseline(cfg, params, h, passes):
             "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN): BASELINE config 1, B=1 LR %dx%d, tau=0, median of %d "
                       "timed passes after warm-up, %d threads chosen from %s on a %d-CPU host" % (h, h, passes, threads, cands, ncpu),
             "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times],
-             "spread_rel": round((max(times) - min(times)) / med, 3)}, lr, out)
+             "spread_rel": round((max(times) - min(times)) / med, 3), "c_port": c_port}, lr, out)
+
+
+def c_port_sample():
+    """The second CPU restatement BASELINE.md section 3 names: oracle/hcflow_ref.c (plain C, scalar loops, ONE core), timed on a
+    bounded sample of the workload -- the RDB growth conv (3x3, 64 -> 32) on one 80x80 feature map, the layer type that makes up
+    87 % of the path's FLOPs -- and projected to a whole image through the path's 2 948 GFLOP (98 % of them in convs)."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    so = os.path.join(ROOT, "oracle", "_build", "libhcflow_ref.so")
+    try:
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+    except (OSError, subprocess.CalledProcessError) as e:
+        return {"skipped": "oracle/_build/libhcflow_ref.so unavailable (%s)" % type(e).__name__}
+    fp = C.POINTER(C.c_float)
+    Bc, Cin, Hc, Wc, Cout = 1, 64, 80, 80, 32
+    rs = np.random.RandomState(0)
+    x = rs.rand(Bc, Cin, Hc, Wc).astype(np.float32)
+    w = (rs.rand(Cout, Cin, 3, 3).astype(np.float32) - 0.5) * 0.1
+    b = np.zeros(Cout, np.float32)
+    o = np.empty((Bc, Cout, Hc, Wc), np.float32)
+    lib.ref_conv2d.argtypes = [fp, fp, fp, fp] + [C.c_int] * 6
+    args = (x.ctypes.data_as(fp), w.ctypes.data_as(fp), b.ctypes.data_as(fp), o.ctypes.data_as(fp), Bc, Cin, Hc, Wc, Cout, 3)
+    lib.ref_conv2d(*args)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib.ref_conv2d(*args)
+        ts.append(time.perf_counter() - t0)
+    gflop = 2.0 * 9 * Cin * Cout * Hc * Wc * Bc / 1e9
+    rate = gflop / min(ts)
+    return {"kind": "port", "what": "oracle/hcflow_ref.c ref_conv2d, scalar C, 1 core", "cores": 1,
+            "sample": "3x3 conv 64 -> 32 on one 80x80 map (%.3f GFLOP), best of 3" % gflop, "gflops": round(rate, 3),
+            "projected_value": round(rate / GFLOP_PER_IMAGE, 6), "unit": "HR images/s (projected: 2948 GFLOP per image at this rate)"}
 
 
 if __name__ == "__main__":

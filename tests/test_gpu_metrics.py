@@ -58,3 +58,39 @@ def test_batch_and_identical_images():
     same = metrics.psnr_ssim(x, x)[0]
     assert same["psnr"] == float("inf") and abs(same["ssim"] - 1.0) <= 1e-12
     assert abs(metrics.diversity([x[0], x[1], x[2]]) - float((torch.stack([x[0], x[1], x[2]]) * 255).std(0).mean())) <= 1e-4
+
+
+def test_batched_evaluation_equals_one_image_at_a_time():
+    """hcflow_amd/loader.py: the reference's per-image test loop (batch 1, test_HCFlow.py:85-182) run on batches -- every
+    number of an image is the one it gets when fed alone (per-sample ops; tau = 0 and seeded samples)."""
+    from hcflow_amd import HCFlowNet_SR, preset, make_params
+    from hcflow_amd.loader import batched_test_loader, evaluate_batch
+    from tests.test_loader_cpu import FakeSet
+    cfg = preset("SR_4X_tiny")
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(make_params(cfg, 11), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.cuda().eval()
+    ds = FakeSet([(12, 16)] * 3 + [(8, 8)] * 2)
+    heats = [0.0, 0.8]
+    def noise_for(b, first):           # the dequantisation noise of dataset item i, whatever batch it lands in
+        return torch.stack([torch.rand(b["GT"].shape[1:], generator=torch.Generator().manual_seed(500 + first + j))
+                            for j in range(b["GT"].shape[0])], 0).cuda()
+    together, alone, k = [], [], 0
+    for b in batched_test_loader(ds, 4):
+        together += evaluate_batch(net, b, heats, n_sample=1, scale=4, noise=noise_for(b, k))
+        k += b["LQ"].shape[0]
+    k = 0
+    for b in batched_test_loader(ds, 1):
+        alone += evaluate_batch(net, b, [0.0], n_sample=1, scale=4, noise=noise_for(b, k))
+        k += 1
+    assert len(together) == len(alone) == 5
+    for t_, a_ in zip(together, alone):
+        assert abs(t_["nll"] - a_["nll"]) <= 1e-6 * max(1.0, abs(a_["nll"]))
+        for k in ("psnr", "ssim", "psnr_y", "ssim_y"):
+            assert abs(t_["lr"][k] - a_["lr"][k]) <= 1e-9 * max(1.0, abs(a_["lr"][k]))
+        for k in ("psnr", "ssim", "bic_psnr", "bic_ssim_y"):
+            assert abs(t_[0.0][k] - a_[0.0][k]) <= 1e-9 * max(1.0, abs(a_[0.0][k])), k
+        assert set(t_[0.8].keys()) >= {"psnr", "ssim", "diversity"}

@@ -1,14 +1,14 @@
 // Stand-alone harness for the Winograd f16x3 convolution (hcflow_amd/csrc/hcf_conv_wino.h): checks it against a naive fp64
 // direct convolution of the same fp32 inputs and times the RDB shapes of config 2 (B = 16, 320^2 / 160^2).
-//   hipcc -O3 --offload-arch=gfx950 -I hcflow_amd/csrc tools/micro/conv_wino.hip -o build/micro/conv_wino && build/micro/conv_wino
+//   hipcc -O3 --offload-arch=gfx950 -I hcflow_amd/csrc -I tools/micro tools/micro/conv_wino.hip -o build/micro/conv_wino && build/micro/conv_wino
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
-#define WINO_WITH_V1 1
 #include "hcf_conv_wino.h"
+#include "hcf_conv_wino_v1.h"      // version 1 of the series (tools/micro only)
 
 using namespace hcf::wino;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
     if (P.res) { a.res1 = res; a.res1_cs = 64; a.res1_c0 = 0; a.rs1 = 0.2f; }
     a.ovf = ovf; a.zeros = reinterpret_cast<const char*>(ovf) + 64;
     unsigned long long* dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); a.dbg = dbg;
-    int rc = launch(a, ncu, 0, ver);
+    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -120,9 +120,9 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) launch(a, ncu, 0, ver);
+      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) launch(a, ncu, 0, ver);
+      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;
