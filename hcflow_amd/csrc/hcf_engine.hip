@@ -872,7 +872,30 @@ struct hcf_engine {
   }
 
   // ConditionalFlow.get_conditional_feature_SR / _Rescaling (ConditionalFlow.py:99-110) -> cfbuf
+  // HCF_TRUNK_MB=n (experiment, profiles/r03_notes.md): the RRDB trunk runs n samples at a time so that a dense block's
+  // 192-channel slab (78.6 MB per sample at 320 x 320) stays inside the 256 MB MALL between its five convs. Off by default:
+  // the persistent Winograd kernels then see 3..6 units per CU and lose more to the ragged last round than the cache gives.
   void run_cond_features(const CondFlow& cf, std::vector<View> u, int H, int W, const Buf& cfbuf, Scratch& sc) {
+    static const int trunk_mb = getenv("HCF_TRUNK_MB") ? atoi(getenv("HCF_TRUNK_MB")) : 0;
+    if (trunk_mb > 0 && trunk_mb < B_ && !taping && !an_active) {
+      const int Bfull = B_;
+      auto shiftv = [&](View v, int b0) { v.p += (size_t)b0 * (H >> v.up) * (W >> v.up) * v.cs; return v; };
+      auto shiftb = [&](Buf b, int b0) { if (b.p) b.p += (size_t)b0 * H * W * b.cs; return b; };
+      for (int b0 = 0; b0 < Bfull; b0 += trunk_mb) {
+        B_ = std::min(trunk_mb, Bfull - b0);
+        std::vector<View> ub;
+        for (const View& v : u) ub.push_back(shiftv(v, b0));
+        Scratch sb = sc;
+        sb.t1 = shiftb(sc.t1, b0); sb.t2 = shiftb(sc.t2, b0); sb.x = shiftb(sc.x, b0); sb.f0 = shiftb(sc.f0, b0);
+        sb.rgrow = shiftb(sc.rgrow, b0);
+        run_cond_features_all(cf, ub, H, W, shiftb(cfbuf, b0), sb);
+      }
+      B_ = Bfull;
+      return;
+    }
+    run_cond_features_all(cf, u, H, W, cfbuf, sc);
+  }
+  void run_cond_features_all(const CondFlow& cf, std::vector<View> u, int H, int W, const Buf& cfbuf, Scratch& sc) {
     const int nf = cfg.rrdb_nf;
     run_conv(cf.conv_first, u, H, W, sc.f0.v(0, nf));
     View cur = sc.f0.v(0, nf);

@@ -123,7 +123,7 @@ def test_replay_of_optimize_parameters_sr(precision):
         kw = {k: ({"hr": hr, "lr": lr}[k] if isinstance(v, tuple) else v) for k, v in c[4].items()}
         _, nll = net(**kw, noise=draws.pop(0)[1].cuda())
         nll = float(g[tag + "_recipe"][0]) * nll.sum()
-        assert abs(float(nll) - float(g[tag + "_logs"][step][0])) <= 2e-4 * abs(float(g[tag + "_logs"][step][0])), (step, float(nll))
+        assert abs(float(nll.detach()) - float(g[tag + "_logs"][step][0])) <= 2e-4 * abs(float(g[tag + "_logs"][step][0])), (step, float(nll.detach()))
         nll.backward()
         _clip(net, g, tag)
         opt.step()

@@ -73,7 +73,7 @@ def test_batched_evaluation_equals_one_image_at_a_time():
         if "ActNorm" in type(m).__name__:
             m.inited = True
     net = net.cuda().eval()
-    ds = FakeSet([(12, 16)] * 3 + [(8, 8)] * 2)
+    ds = FakeSet([(12, 16)] * 3 + [(16, 12)] * 2)        # LR >= 11 pixels a side: the SSIM window (util.py:907)
     heats = [0.0, 0.8]
     def noise_for(b, first):           # the dequantisation noise of dataset item i, whatever batch it lands in
         return torch.stack([torch.rand(b["GT"].shape[1:], generator=torch.Generator().manual_seed(500 + first + j))
