@@ -43,7 +43,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec
 GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
-# (label, taps, n-tiles, kind) of the conv instantiations a pass launches; kind: see include/hcflow.h hcf_conv_time_ms
+# (label, taps, n-tiles, kind) of the conv instantiations a pass launches; kind: see include/hcflow.h hcf_conv_time_ms (5 = the persistent small-K FCN kernel)
 # + the keys of that instantiation in profiles/rNN_traffic_pmc.json (tools/pmc_traffic.py)
 VARIANTS = {
     "f16x3": [("hcf::f16x3::conv_f16x3_kernel<2,true,false,false,0,8,false> plain 3x3, 33..64 out-ch", 9, 2, 0, ["f16x3<2>"]),
@@ -51,6 +51,7 @@ VARIANTS = {
               ("hcf::wino::conv_wino4_kernel<1|2> Winograd F(2x2,3x3) form, 64 out-ch, >= 128 in-ch (RDB conv5)", 9, 2, 4, ["wino4<1>", "wino4<2>"]),
               ("hcf::wino::conv_wino2_kernel<0> Winograd F(2x2,3x3) form, 32 out-ch, >= 128 in-ch (RDB conv3 / conv4)", 9, 1, 4, ["wino<0>"]),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,*,true,0,8,false> FCN conv1 3x3 + conv2 1x1 (FUSE2)", 9, 2, 1, ["f16x3<2>+fuse2"]),
+              ("hcf::fcn12::fcn12_kernel<false> FCN conv1 3x3 (<= 16 in-ch) + conv2 1x1, persistent, weights in registers", 9, 2, 5, ["fcn12"]),
               ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2, []),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,true,false,0,8,false> conv_first on upsampled LR (UP)", 9, 2, 3, ["f16x3<2>+up"]),
               ("hcf::conv_mfma_kernel<1,*,true> 1x1 convs left on the exact fp32 kernel", 1, 0, -1, [])],
@@ -180,13 +181,14 @@ def main():
         traffic, tnote = None, ("not measured in this run (PMC counters need separate rocprofv3 --pmc passes: "
                                 "profiles/ holds them per round)")
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")))
+            tfile = next(f for f in ("r03_traffic_pmc.json", "r02_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             ents = [tj["kernels"][k] for k in dom["_tkeys"] if k in tj["kernels"]]
             if ents and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:       # launch-weighted mean over the instantiation's keys
                 traffic = round(sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) /
                                 sum(e["launches_sampled"] for e in ents) / 1e9, 4)
-                tnote = "GB per launch, REPLAYED from profiles/r02_traffic_pmc.json (" + tj["source"] + "), not measured in this run"
-        except (OSError, KeyError, ValueError):
+                tnote = "GB per launch, REPLAYED from profiles/" + tfile + " (" + tj["source"] + "), not measured in this run"
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         block = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -66,6 +66,16 @@ int main(int argc, char** argv) {
       {"rdb conv4 L0 160->32  @320 B=4", 4, 320, 320, 64, 96, 32, 2, false},
       {"rdb conv1 L1  64->32  @160", 16, 160, 160, 64, 0, 32, 2, false},
       {"rdb conv5 L1 192->64  @160", 16, 160, 160, 64, 128, 64, 0, true},
+      // components of the "fat launch" schedule of an RDB (profiles/r03_notes.md): A = conv1 + conv2|x0 (64 -> 64),
+      // B / D = completion of conv2 / conv4 (32 -> 32, + stored partial read through the residual slot),
+      // C = conv3 + conv4|[x0 x1 x2] (128 -> 64); E = conv5 as today
+      {"fat A L0  64->64  @320", 16, 320, 320, 64, 0, 64, 2, false},
+      {"fat B L0  32->32  @320 +partial", 16, 320, 320, 32, 0, 32, 2, true},
+      {"fat C L0 128->64  @320", 16, 320, 320, 64, 64, 64, 2, false},
+      {"rdb conv3 L0 128->32 @320", 16, 320, 320, 64, 64, 32, 2, false},
+      {"fat A L1  64->64  @160", 16, 160, 160, 64, 0, 64, 2, false},
+      {"fat B L1  32->32  @160 +partial", 16, 160, 160, 32, 0, 32, 2, true},
+      {"fat C L1 128->64  @160", 16, 160, 160, 64, 64, 64, 2, false},
   };
   const int nprob = sizeof(probs) / sizeof(probs[0]);
   for (int pi = 0; pi < nprob; ++pi) {

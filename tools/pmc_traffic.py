@@ -31,6 +31,9 @@ def short_name(k):
         if up == "true":
             tag += "+up"
         return tag
+    m = re.search(r"fcn12_kernel<(true|false)>", k)
+    if m:
+        return "fcn12" + ("+pre" if m.group(1) == "true" else "")
     m = re.search(r"conv_wino4_kernel<(\d)>", k)
     if m:
         return "wino4<%s>" % m.group(1)         # the 64-output-channel Winograd kernel (RDB conv5: 1 or 2 residual inputs)
@@ -61,7 +64,7 @@ def collect(d, counter):
 
 def main(fetch_dir, write_dir):
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 1 "
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 5 --warmup 2 --no-other-precision "
                      "--warmup 1`, B=16; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128 B "
                      "request); averaged over all launches of the kernel in the run (tools/pmc_traffic.py)",
            "kernels": {}}

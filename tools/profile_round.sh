@@ -15,7 +15,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py
 python $ROOT/tools/rocpd_summary.py $OUT/kt > $OUT/kernel_stats.txt 2>> $OUT/kt.log
 rm -rf $OUT/kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-exact-check > $OUT/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check --no-other-precision > $OUT/pmc_$c.log 2>&1
 done
 python $ROOT/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/traffic_pmc.json 2> $OUT/traffic.err
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
