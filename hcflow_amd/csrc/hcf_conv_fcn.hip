@@ -37,7 +37,11 @@ constexpr int F2S = 272;                     // bytes per pixel of the layer-1 t
                                              // the natural 256 every lane of a group lands in the same four banks
 constexpr int X_BYTES = TH * TW * F2S;                                         // 34 816: layer-1 tile (split f16) / fp32 output tile (32 KB)
 constexpr int W2_BYTES = 4 * 2 * 2 * BHALF;                                    // 16 384: conv2 pack [kc][plane][k-half][64 n][8 halves]
-constexpr int LDS_BYTES = X_BYTES + W2_BYTES;                                  // 51 200 (the conv1 weights live in registers)
+#ifndef FCN12_W1_LDS
+#define FCN12_W1_LDS 0   // 1: conv1's pack in LDS too (36 KB) instead of registers (A/B knob of tools/micro/fcn12_bench.hip)
+#endif
+constexpr int W1_BYTES = 9 * 2 * 2 * BHALF;                                    // 36 864
+constexpr int LDS_BYTES = X_BYTES + (FCN12_W1_LDS ? W1_BYTES : W2_BYTES);      // (with conv1's pack in LDS conv2's fragments come from L1)  // 51 200 (the conv1 weights live in registers)
 constexpr float SPLIT = 2048.f;
 #ifndef FCN12_ABL
 #define FCN12_ABL 0      // timing ablations of tools/micro/fcn12_bench.hip (results invalid); the library is built with 0
@@ -93,21 +97,40 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
   // conv1's B fragments of this wave's n tile (9 taps x 2 planes x 4 VGPRs) live in REGISTERS for the life of the block (the
   // block is persistent): the LDS pipe is what bounds this kernel, and re-reading them per tile was a quarter of its traffic.
   // conv2's 16 KB pack stays in LDS (8 fragment reads per tile; in registers too the kernel spills).
+#if FCN12_W1_LDS
+  {
+    const gf4ptr wq4 = (gf4ptr)uniform_ptr(a.wpack);
+#pragma unroll
+    for (int s = 0; s < W1_BYTES / 16 / 256; ++s) *reinterpret_cast<f32x4*>(lds + X_BYTES + (tid + 256 * s) * 16) = wq4[tid + 256 * s];
+  }
+  const char* const w1l = lds + X_BYTES + half * BHALF + oc * 16;
+#define FCN12_W1A(T) (*reinterpret_cast<const f16x8*>(w1l + (T) * (4 * BHALF)))
+#define FCN12_W1B(T) (*reinterpret_cast<const f16x8*>(w1l + (T) * (4 * BHALF) + 2 * BHALF))
+#else
+#define FCN12_W1A(T) w1a[T]
+#define FCN12_W1B(T) w1b[T]
+#endif
   f16x8 w1a[9], w1b[9];
   {
     const char __attribute__((address_space(1)))* const wq =
         (const char __attribute__((address_space(1)))*)uniform_ptr(a.wpack) + half * BHALF + oc * 16;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
-      w1a[tp] = *(const f16x8 __attribute__((address_space(1)))*)(wq + tp * (4 * BHALF));
-      w1b[tp] = *(const f16x8 __attribute__((address_space(1)))*)(wq + tp * (4 * BHALF) + 2 * BHALF);
+      if (!FCN12_W1_LDS) {
+        w1a[tp] = *(const f16x8 __attribute__((address_space(1)))*)(wq + tp * (4 * BHALF));
+        w1b[tp] = *(const f16x8 __attribute__((address_space(1)))*)(wq + tp * (4 * BHALF) + 2 * BHALF);
+      }
     }
     // conv2 pack: 16 KB, copied into LDS once (behind the exchange region)
     const gf4ptr vq = (gf4ptr)uniform_ptr(a.w2);
+    if (!FCN12_W1_LDS) {
 #pragma unroll
-    for (int s = 0; s < W2_BYTES / 16 / 256; ++s) *reinterpret_cast<f32x4*>(lds + X_BYTES + (tid + 256 * s) * 16) = vq[tid + 256 * s];
+      for (int s = 0; s < W2_BYTES / 16 / 256; ++s) *reinterpret_cast<f32x4*>(lds + X_BYTES + (tid + 256 * s) * 16) = vq[tid + 256 * s];
+    }
   }
   const char* const w2l = lds + X_BYTES + half * BHALF + oc * 16;
+  const char __attribute__((address_space(1)))* const w2g =
+      (const char __attribute__((address_space(1)))*)uniform_ptr(a.w2) + half * BHALF + oc * 16;
 
   f32x4 stg[NSLOT];
   int tb = 0, ty0 = 0, tx0 = 0;                       // coordinates of the tile whose halo sits in stg
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
       }
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const f16x8 b1 = w1a[dy * 3 + dx], b2 = w1b[dy * 3 + dx];
+        const f16x8 b1 = FCN12_W1A(dy * 3 + dx), b2 = FCN12_W1B(dy * 3 + dx);
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rhi[m + dy], b1, acc[m], 0, 0, 0);
 #pragma unroll
@@ -260,8 +283,10 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      const f16x8 b1 = *reinterpret_cast<const f16x8*>(w2l + (kc * 2 + 0) * (2 * BHALF));
-      const f16x8 b2 = *reinterpret_cast<const f16x8*>(w2l + (kc * 2 + 1) * (2 * BHALF));
+      const f16x8 b1 = FCN12_W1_LDS ? *(const f16x8 __attribute__((address_space(1)))*)(w2g + (kc * 2 + 0) * (2 * BHALF))
+                                    : *reinterpret_cast<const f16x8*>(w2l + (kc * 2 + 0) * (2 * BHALF));
+      const f16x8 b2 = FCN12_W1_LDS ? *(const f16x8 __attribute__((address_space(1)))*)(w2g + (kc * 2 + 1) * (2 * BHALF))
+                                    : *reinterpret_cast<const f16x8*>(w2l + (kc * 2 + 1) * (2 * BHALF));
       f16x8 ahi[2], alo[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
