@@ -33,6 +33,7 @@ SYMBOLS = [
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
     "hcf_train_select_tape", "hcf_train_forward_rescale", "hcf_train_backward_rescale",
     "hcf_debug_range_probe", "hcf_debug_range_probe_read",
+    "hcf_aux_conv2d_workspace", "hcf_aux_conv2d", "hcf_aux_conv2d_backward",
 ]
 
 
@@ -103,6 +104,10 @@ def load() -> C.CDLL:
     lib.hcf_train_select_tape.argtypes = [vp, i32]
     lib.hcf_train_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, C.c_uint32, vp]
     lib.hcf_train_backward_rescale.argtypes = [vp, fp, fp, fp, fp, i64, vp]
+    lib.hcf_aux_conv2d_workspace.argtypes = [i32, i32, i32, i32, i32, i32]
+    lib.hcf_aux_conv2d_workspace.restype = C.c_size_t
+    lib.hcf_aux_conv2d.argtypes = [fp, i32, i32, i32, i32, i32, fp, fp, i32, i32, i32, fp, i32, vp, C.c_size_t, i32, vp]
+    lib.hcf_aux_conv2d_backward.argtypes = [fp, i32, i32, i32, i32, i32, fp, i32, i32, fp, i32, fp, i32, fp, vp, C.c_size_t, i32, vp]
     lib.hcf_debug_range_probe.argtypes = [vp, i32]
     lib.hcf_debug_range_probe_read.argtypes = [vp, i32, C.c_char_p, i32, C.POINTER(f32), C.POINTER(i32)]
     lib.hcf_bind_param_device.argtypes = [vp, C.c_char_p, fp]
@@ -125,7 +130,7 @@ def load() -> C.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("hcf_destroy", "hcf_last_error", "hcf_workspace_bytes", "hcf_weight_bytes",
-                        "hcf_fallback_count", "hcf_debug_last_clock_mhz"):
+                        "hcf_fallback_count", "hcf_debug_last_clock_mhz", "hcf_aux_conv2d_workspace"):
             fn.restype = C.c_int
     _lib = lib
     return lib

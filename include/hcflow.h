@@ -273,6 +273,24 @@ int hcf_op_gauss_logp(const float* h, const float* x, float* out_logp, int32_t B
 int hcf_op_gauss_sample(const float* h, const float* eps, float tau, uint64_t seed, float* out, int32_t B, int32_t C,
                         int32_t H, int32_t W, int32_t rescale, hcf_stream_t stream);
 
+/* ---- auxiliary nets of the HCFlow+ / ++ recipes (reference: Discriminator_VGG_160 / VGGFeatureExtractor,
+ *      codes/models/modules/discriminator_vgg_arch.py:68-157; used by HCFlow_SR_model.py:75-95,219-285) ------------------
+ * Stride-1 "same" convolution (k = 3 or 1) and its gradients on DEVICE tensors with the flow's own conv / weight-gradient
+ * kernels: x, y, g, dx are dense NHWC fp32 [B][H][W][cs] (cs % 4 == 0, 16-byte aligned), w is the PyTorch-layout weight
+ * [cout][cin][k][k] in device memory (packs are rebuilt on the device per call), bias [cout] or NULL.
+ *   hcf_aux_conv2d:          y[..., 0:cout] = act(conv(x[..., 0:cin], w) + bias), act 0 none / 1 relu / 2 leaky relu 0.2
+ *   hcf_aux_conv2d_backward: dx[..., 0:cin] = dL/dx (nullable), dw = dL/dw given g = dL/d(conv output)
+ * `work`: device scratch of hcf_aux_conv2d_workspace(...) bytes; with HCF_PRECISION_F16X3 (3x3 forward only) the int at
+ * work[0] is raised when an input leaves the f16 range (the caller zeroes it before a network pass and reads it after).
+ * The discriminator's 4x4 stride-2 convs run as squeeze2d + 3x3 conv with a re-indexed weight (hcflow_amd/gan.py). */
+size_t hcf_aux_conv2d_workspace(int32_t cin, int32_t cout, int32_t k, int32_t B, int32_t H, int32_t W);
+int hcf_aux_conv2d(const float* x, int32_t cs_in, int32_t cin, int32_t B, int32_t H, int32_t W, const float* w,
+                   const float* bias, int32_t cout, int32_t k, int32_t act, float* y, int32_t cs_out, void* work,
+                   size_t work_bytes, int32_t precision, hcf_stream_t stream);
+int hcf_aux_conv2d_backward(const float* x, int32_t cs_in, int32_t cin, int32_t B, int32_t H, int32_t W, const float* w,
+                            int32_t cout, int32_t k, const float* g, int32_t cs_g, float* dx, int32_t cs_dx, float* dw,
+                            void* work, size_t work_bytes, int32_t precision, hcf_stream_t stream);
+
 /* Range-headroom probe of the f16x3 path (tools/range_headroom.py): while enabled, every conv launch of the following passes
  * also records max |x| over its input windows and -- for layers that own a Winograd pack -- max |B^T d B| over the F(2x2,3x3)
  * input patches, i.e. the values the split has to represent (f16 limit 65504). hcf_debug_range_probe_read returns record

@@ -633,6 +633,57 @@ def gen_checkpoint_fixture(name, preset_name, ref_sr, ref_rs, seed):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+
+def gen_gan_fixture():
+    """The reference's Discriminator_VGG_160 (discriminator_vgg_arch.py:68-107) and GANLoss (loss.py:19-51) run here on CPU: the
+    module is built under torch.manual_seed (its own default initialisation; our class builds the same modules in the same
+    order, so the GPU box regenerates identical parameters -- `param_digest` checks it), one train()-mode forward / backward
+    of the discriminator step of HCFlow_SR_model.optimize_parameters (:258-285, gan_type 'gan') on seeded inputs; stored:
+    key / shape table, outputs, losses, per-parameter gradient digests, the BatchNorm running statistics after the step."""
+    import types
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tv.models)
+    import importlib.util as ilu
+    spec = ilu.spec_from_file_location("ref_discriminator_vgg_arch", os.path.join(REF, "models", "modules", "discriminator_vgg_arch.py"))
+    D = ilu.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    spec2 = ilu.spec_from_file_location("ref_loss", os.path.join(REF, "models", "modules", "loss.py"))
+    Lm = ilu.module_from_spec(spec2)
+    spec2.loader.exec_module(Lm)
+    torch.manual_seed(123)
+    net = D.Discriminator_VGG_160(3, 64)
+    net.train()
+    sd = net.state_dict()
+    out = {"keys": np.array(list(sd.keys())), "shapes": np.array([",".join(str(v) for v in t_.shape) for t_ in sd.values()]),
+           "seed": 123}
+    out["param_digest"] = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd.values()])
+    g = torch.Generator().manual_seed(7)
+    real = torch.rand(2, 3, 160, 160, generator=g)
+    fake = torch.rand(2, 3, 160, 160, generator=g)
+    cri = Lm.GANLoss("gan", 1.0, 0.0)
+    pred_real = net(real)
+    pred_fake = net(fake)
+    l_real, l_fake = cri(pred_real, True), cri(pred_fake, False)
+    (l_real + l_fake).backward()
+    out.update(input_seed=7, pred_real=np_(pred_real), pred_fake=np_(pred_fake), l_real=np.float64(float(l_real)),
+               l_fake=np.float64(float(l_fake)))
+    out["grad_digest"] = np.array([grad_digest(np_(p.grad), i) for i, (k, p) in enumerate(net.named_parameters())])
+    out["grad_keys"] = np.array([k for k, _ in net.named_parameters()])
+    for k, v in net.state_dict().items():
+        if "running_" in k and k.startswith("bn4_1"):
+            out["after_" + k] = np_(v)
+    # GANLoss table: every type on a fixed logit vector
+    x = torch.linspace(-2, 2, 7).view(7, 1)
+    for t_ in ("gan", "ragan", "lsgan", "wgan-gp"):
+        c = Lm.GANLoss(t_, 1.0, 0.0)
+        out["ganloss_" + t_] = np.array([float(c(x, True)), float(c(x, False))])
+    path = os.path.join(HERE, "gan_discriminator.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "pred_real", np_(pred_real).ravel(), "losses", float(l_real), float(l_fake))
+
+
 def main():
     torch.set_num_threads(8)
     ref_sr, ref_rs = import_reference()
@@ -653,6 +704,10 @@ def main():
         gen_real_net_fixture("net_rescale_real", "Rescaling_DF2K_4X", ref_sr, ref_rs, img_tensor(im["butterfly_lr"]),
                              img_tensor(im["butterfly_hr"]), seed=75, taus=(0.0, 1.0), images="butterfly")
         if only == "real":
+            return
+    if only in ("all", "gan"):
+        gen_gan_fixture()
+        if only == "gan":
             return
     if only in ("all", "ckpt"):
         gen_checkpoint_fixture("ckpt_sr4_micro", "SR_4X_micro", ref_sr, ref_rs, seed=81)
