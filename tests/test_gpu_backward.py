@@ -450,3 +450,21 @@ def test_training_api_error_paths():
     assert bool(torch.isfinite(out).all())
     nll2.backward()                                    # inference in between used its own arena: the tape is intact
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters() if p.grad is not None)
+
+
+def test_weight_gradient_f16x3_falls_back_when_the_input_leaves_the_f16_range():
+    """the f16x3 weight-gradient kernel splits X without a scale, so an |x| >= 65504 that no forward range check
+    covered (1x1 convs, > 64 output channels, the per-op entry point) must take the fp32 kernel: finite and equal to exact."""
+    from hcflow_amd import ops
+    g = _gen(5)
+    x = torch.randn(2, 32, 24, 40, generator=g)
+    x[1, 7, 3, 9] = 7.0e4
+    gy = torch.randn(2, 32, 24, 40, generator=g)
+    w0 = torch.zeros(32, 32, 3, 3)
+    _, dw_exact, _ = ops.conv2d_backward([x.cuda()], w0, gy.cuda(), need_input_grads=False)
+    ops.set_precision("f16x3")
+    try:
+        _, dw, _ = ops.conv2d_backward([x.cuda()], w0, gy.cuda(), need_input_grads=False)
+    finally:
+        ops.set_precision("exact")
+    assert bool(torch.isfinite(dw).all()) and torch.equal(dw, dw_exact)

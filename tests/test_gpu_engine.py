@@ -164,3 +164,20 @@ def test_dataparallel_replica_forward_and_backward():
     wrapped = torch.nn.DataParallel(net, device_ids=[0])
     _, nll3 = wrapped(hr=hr, lr=lr, reverse=False, noise=noise)
     assert float(nll3.detach()) == float(nll.detach())
+
+
+def test_cond_cache_is_not_served_to_a_new_tensor_at_a_recycled_address():
+    """`for lr in loader: net(lr=lr.cuda(), cache_cond=True)` -- the caching allocator hands the freed LR batch's
+    address (and _version 0) to the next same-shaped batch; the cache key holds its tensor, so the new batch recomputes."""
+    cfg, net = _net("SR_4X_tiny", 12, "f16x3")
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        seen = set()
+        for i in range(4):
+            lr = torch.rand(2, 3, 8, 12, generator=g).cuda()
+            seen.add(lr.data_ptr())
+            got = net(lr=lr, eps_std=0.7, reverse=True, seed=40 + i, cache_cond=True)
+            want = net(lr=lr.clone(), eps_std=0.7, reverse=True, seed=40 + i)
+            assert torch.equal(got, want), i
+            del lr
+        # (whether or not the allocator recycled an address in this run, every batch got its own features)
