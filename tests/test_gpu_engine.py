@@ -171,13 +171,15 @@ def test_cond_cache_is_not_served_to_a_new_tensor_at_a_recycled_address():
     address (and _version 0) to the next same-shaped batch; the cache key holds its tensor, so the new batch recomputes."""
     cfg, net = _net("SR_4X_tiny", 12, "f16x3")
     g = torch.Generator().manual_seed(6)
+    lrs = [torch.rand(2, 3, 8, 12, generator=g) for _ in range(4)]
     with torch.no_grad():
-        seen = set()
-        for i in range(4):
-            lr = torch.rand(2, 3, 8, 12, generator=g).cuda()
-            seen.add(lr.data_ptr())
+        wants = [net(lr=l.cuda(), eps_std=0.7, reverse=True, seed=40 + i) for i, l in enumerate(lrs)]      # uncached
+        ptrs = []
+        for i, l in enumerate(lrs):                       # nothing but cached calls in this loop: the key stays live
+            lr = l.cuda()
+            ptrs.append(lr.data_ptr())
             got = net(lr=lr, eps_std=0.7, reverse=True, seed=40 + i, cache_cond=True)
-            want = net(lr=lr.clone(), eps_std=0.7, reverse=True, seed=40 + i)
-            assert torch.equal(got, want), i
-            del lr
-        # (whether or not the allocator recycled an address in this run, every batch got its own features)
+            assert torch.equal(got, wants[i]), i
+            del lr, got
+        # (the module keeps the keyed tensor alive, so the allocator CANNOT hand its address to the next batch)
+        assert len(set(ptrs)) == len(ptrs)
