@@ -183,3 +183,33 @@ def test_cond_cache_is_not_served_to_a_new_tensor_at_a_recycled_address():
             del lr, got
         # (the module keeps the keyed tensor alive, so the allocator CANNOT hand its address to the NEXT batch)
         assert all(a != b for a, b in zip(ptrs, ptrs[1:]))
+
+
+def test_trunk_microbatch_knob_is_bit_identical(monkeypatch):
+    """HCF_TRUNK_MB (the MALL experiment of profiles/r03_notes.md, off by default) only re-orders the RRDB trunk over sub-batches:
+    every op is per sample, so the images must not change. The knob is read once per process: run the comparison in a child."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch, contextlib\n"
+        "sys.path.insert(0, '.')\n"
+        "from hcflow_amd import HCFlowNet_SR, preset, make_params\n"
+        "cfg = preset('SR_4X_tiny')\n"
+        "with contextlib.redirect_stdout(sys.stderr):\n"
+        "    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)\n"
+        "net.load_state_dict(make_params(cfg, 11), strict=True)\n"
+        "[setattr(m, 'inited', True) for m in net.modules() if 'ActNorm' in type(m).__name__]\n"
+        "net = net.cuda().eval()\n"
+        "lr = torch.rand(6, 3, 24, 40, generator=torch.Generator().manual_seed(2)).cuda()\n"
+        "with torch.no_grad():\n"
+        "    out = net(lr=lr, eps_std=0.8, reverse=True, seed=9)\n"
+        "print('DIGEST %.10e %.10e' % (float(out.double().sum()), float((out.double() ** 2).sum())))\n")
+    import os
+    outs = []
+    for mb in ("0", "4"):
+        env = dict(os.environ, HCF_TRUNK_MB=mb)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert outs[0] == outs[1], outs

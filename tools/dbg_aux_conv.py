@@ -1,3 +1,5 @@
+"""Debug aid: hcf_aux_conv2d / hcf_aux_conv2d_backward on single layers against fp64 torch (y, dx, dw, db) and run-to-run bit
+identity (GPU box); the test form is tests/test_gpu_gan.py::test_aux_conv_op_matches_torch."""
 import sys, torch, torch.nn.functional as F
 sys.path.insert(0, '.')
 from hcflow_amd import gan

@@ -1,3 +1,6 @@
+"""Per-launch durations (start order) of the conv / flow kernels of the LAST third of a rocprofv3 --kernel-trace run:
+    rocprofv3 --kernel-trace -d /tmp/kt -- python bench.py --steps 1 --warmup 2 ...; python tools/rocpd_percall.py /tmp/kt
+-> profiles/r03_percall_trace.txt"""
 import glob, os, sqlite3, sys
 path = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*_results.db"), recursive=True))[0]
 cur = sqlite3.connect(path).cursor()
