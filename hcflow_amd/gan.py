@@ -109,13 +109,14 @@ class _ConvNHWC(torch.autograd.Function):
             g = g * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
         need_dx = ctx.needs_input_grad[0]
         dx = torch.zeros_like(x) if need_dx else None
-        dw = torch.empty_like(w)
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None       # frozen weights (VGG; netD during the G step): skipped
         with torch.cuda.device(x.device):
             rc = lib.hcf_aux_conv2d_backward(x.data_ptr(), cs, cin, B, H, W, w.data_ptr(), cout, k, g.data_ptr(), g.shape[3],
-                                             None if dx is None else dx.data_ptr(), cs, dw.data_ptr(), C.c_void_p(wk.data_ptr()),
+                                             None if dx is None else dx.data_ptr(), cs, None if dw is None else dw.data_ptr(),
+                                             C.c_void_p(wk.data_ptr()),
                                              wk.numel(), prec, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         _lib.check(rc, None, "hcf_aux_conv2d_backward")
-        db = g[..., :cout].sum(dim=(0, 1, 2)) if has_bias else None
+        db = g[..., :cout].sum(dim=(0, 1, 2)) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None
 
 
