@@ -48,8 +48,10 @@ GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> 
 VARIANTS = {
     "f16x3": [("hcf::f16x3::conv_f16x3_kernel<2,true,false,false,0,8,false> plain 3x3, 33..64 out-ch", 9, 2, 0, ["f16x3<2>"]),
               ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,0,8,false> plain 3x3, <=32 out-ch", 9, 1, 0, ["f16x3<1>"]),
-              ("hcf::wino::conv_wino4_kernel<1|2> Winograd F(2x2,3x3) form, 64 out-ch, >= 128 in-ch (RDB conv5)", 9, 2, 4, ["wino4<1>", "wino4<2>"]),
-              ("hcf::wino::conv_wino2_kernel<0> Winograd F(2x2,3x3) form, 32 out-ch, >= 128 in-ch (RDB conv3 / conv4)", 9, 1, 4, ["wino<0>"]),
+              ("hcf::wino::conv_wino4_kernel<0|1|2> Winograd F(2x2,3x3) form, 64 out-ch: RDB conv5, trunk convs, and the fat launches "
+               "(conv3 + conv4's old-input part; at 160^2 also conv1 + conv2's)", 9, 2, 4, ["wino4<0>", "wino4<1>", "wino4<2>"]),
+              ("hcf::wino::conv_wino2_kernel<0|3> Winograd F(2x2,3x3) form, 32 out-ch: RDB conv1 / conv2 and the 32 -> 32 completions of "
+               "the fat launches", 9, 1, 4, ["wino<0>", "wino<3>"]),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,*,true,0,8,false> FCN conv1 3x3 + conv2 1x1 (FUSE2)", 9, 2, 1, ["f16x3<2>+fuse2"]),
               ("hcf::fcn12::fcn12_kernel<false> FCN conv1 3x3 (<= 16 in-ch) + conv2 1x1, persistent, weights in registers", 9, 2, 5, ["fcn12"]),
               ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2, []),

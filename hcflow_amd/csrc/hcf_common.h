@@ -62,6 +62,9 @@ struct ConvArgs {
   const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
   unsigned long long* dbg; // HCF_CONV_TIMERS builds only (tools/conv_bench.py): phase timers of a few mid-grid blocks
   int vec_epi;             // f16x3 kernel, set by the launcher: out / residual views allow 16-byte accesses -> LDS-transposed epilogue
+  // Winograd kernels only ("fat" dense-block launches, hcf_engine.hip run_rdb): out2.p != null -> output channels [32, 64) go to
+  // out2 with activation act_t2 instead of `out`; res1_pre != 0 -> res1 is a stored partial sum added BEFORE bias / activation
+  View out2; int act_t2; int res1_pre;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -84,8 +87,9 @@ int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st);
 int launch_fcn12(const ConvArgs& a, hipStream_t st);
 // Winograd F(2x2,3x3) form of the same f16x3 conv (hcf_conv_wino.hip): eligible layers only (pack size 0 otherwise);
 // HCF_ERR_UNSUPPORTED when the call cannot take it (upsampled source, unaligned views, > 2^24 pixels): use the direct kernel
-size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out);
+size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out, int min_cin = -1);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
+bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st);   // pack rebuilt from device weights
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------

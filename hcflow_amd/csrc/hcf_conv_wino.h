@@ -59,6 +59,11 @@ struct Args {
   float* out; int out_cs, out_c0, cout;
   const float* res1; int res1_cs, res1_c0; float rs1;      // y = res2 + rs2 * (res1 + rs1 * act((acc + bias) * scale))
   const float* res2; int res2_cs, res2_c0; float rs2;
+  // "fat" dense-block launches (hcf_engine.hip run_rdb): the 64-channel kernel may route its second 32-channel tile to another
+  // tensor with its own activation (conv k's outputs + the old-input part of conv k+1 as ONE launch), and the 32-channel kernel
+  // may add a stored partial sum BEFORE bias / activation (conv k+1's completion): pre != null -> res1 / res2 are unused.
+  float* out2; int out2_cs, out2_c0, act2;                  // 64-channel kernel only; null: both tiles go to `out`
+  const float* pre; int pre_cs, pre_c0;                     // 32-channel kernel only
   int* ovf;
   const char* zeros;       // >= 64 bytes of zeros
   unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
@@ -447,8 +452,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
             const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
             oks[sgrp][ob] = yy < H && xx < W;
             pixs[sgrp][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
-            if (RES >= 1) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[sgrp][ob] * a.res1_cs + a.res1_c0 + cb);
+            if (RES == 1 || RES == 2) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[sgrp][ob] * a.res1_cs + a.res1_c0 + cb);
             if (RES == 2) rv2[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[sgrp][ob] * a.res2_cs + a.res2_c0 + cb);
+            if (RES == 3) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.pre + pixs[sgrp][ob] * a.pre_cs + a.pre_c0 + cb);
           }
         }
         if (oa == 1) __builtin_amdgcn_s_barrier(); // round 0's buffer has been read
@@ -484,9 +490,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
             for (int e = 0; e < 4; ++e) {
               const float yv = y0[e] + y1[e];
               chk = fmaf(yv, 0.f, chk);
-              const float z = fmaf(yv, ms[e], bs[e]);
+              float z = fmaf(yv, ms[e], bs[e]);
+              if (RES == 3) z = fmaf(rv1[sgrp][ob][e], ms[e] * 2048.f, z);      // stored partial sum, scaled like the conv sum
               v[e] = fmaxf(z, slope * z);           // none / relu / leaky relu for slope 1 / 0 / 0.2 (a non-finite z trips chk)
-              if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[sgrp][ob][e]);
+              if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[sgrp][ob][e]);
               if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[sgrp][ob][e]);
             }
             if (oks[sgrp][ob] && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pixs[sgrp][ob] * a.out_cs + a.out_c0 + cb) = v;
@@ -654,6 +661,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   ++uc;
   int g = 0;
   const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+  const float slope2 = a.act2 == 1 ? 0.f : a.act2 == 2 ? 0.2f : 1.f;
 
   while (true) {
     f32x16 acc[4][2];
@@ -802,6 +810,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
         for (int bb = 0; bb < 2; ++bb) R[x][bb] = *reinterpret_cast<const f32x4*>(xbuf + ((x * 2 + bb) * 4) * 1024 + rpos);
       const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + cb * 4);
       const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 256 + cb * 4);
+      const bool split_t = (nt == 1) && a.out2 != nullptr;         // second tile routed to its own tensor / activation
+      const float slope_t = split_t ? slope2 : slope;
 #pragma unroll
       for (int oa = 0; oa < 2; ++oa)
 #pragma unroll
@@ -812,11 +822,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
             const float yv = oa ? (R[1][ob][e] - R[2][ob][e]) - R[3][ob][e] : (R[0][ob][e] + R[1][ob][e]) + R[2][ob][e];
             chk = fmaf(yv, 0.f, chk);
             const float z = fmaf(yv, ms[e], bs[e]);
-            v[e] = fmaxf(z, slope * z);
+            v[e] = fmaxf(z, slope_t * z);
             if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
             if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
           }
-          if (oks[oa][ob] && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
+          if (oks[oa][ob] && cb < a.cout) {
+            if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pixs[oa][ob] * a.out2_cs + a.out2_c0 + (cb - 32)) = v;
+            else *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
+          }
         }
     }
     if (__any(chk != chk)) {
@@ -865,11 +878,13 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
   const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
   // (the opt-in to > 64 KB of dynamic LDS is per device: several GPUs in one process, e.g. nn.DataParallel replicas)
-  static bool attr_dev[64][3][3] = {};
+  static bool attr_dev[64][3][4] = {};
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return -2;
-  bool (&attr)[3][3] = attr_dev[dev_];
-  const int res = a.res2 ? 2 : a.res1 ? 1 : 0;
+  bool (&attr)[3][4] = attr_dev[dev_];
+  if (a.pre && (version != 2 || a.res1 || a.res2 || ((a.pre_cs | a.pre_c0) & 3) || (reinterpret_cast<uintptr_t>(a.pre) & 15))) return -6;
+  if (a.out2 && (version != 4 || a.res1 || ((a.out2_cs | a.out2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out2) & 15))) return -6;
+  const int res = a.pre ? 3 : a.res2 ? 2 : a.res1 ? 1 : 0;
   const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
   const int vi = (version == 2) ? 1 : (version == 4) ? 2 : 0;
   auto go = [&](auto fn, int threads) {
@@ -888,6 +903,7 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (version == 2) {
     if (res == 0) return go(conv_wino2_kernel<0>, 512);
     if (res == 1) return go(conv_wino2_kernel<1>, 512);
+    if (res == 3) return go(conv_wino2_kernel<3>, 512);
     return go(conv_wino2_kernel<2>, 512);
   }
   return -6;

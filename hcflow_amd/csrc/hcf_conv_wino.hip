@@ -9,9 +9,10 @@
 namespace hcf {
 
 // w: PyTorch [cout][cin][3][3]; bytes of the pack (or 0 when the layer is not eligible / a weight leaves the f16 range)
-size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out) {
+size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out, int min_cin_arg) {
   out.clear();
-  static const int min_cin = getenv("HCF_WINO_MIN_CIN") ? atoi(getenv("HCF_WINO_MIN_CIN")) : 64;    // experiment knob, read once (bench A/B: 128 -> 112.2, 96 -> 113.5, 64 -> 114.5 img/s)
+  static const int min_cin_env = getenv("HCF_WINO_MIN_CIN") ? atoi(getenv("HCF_WINO_MIN_CIN")) : 64;    // experiment knob, read once (bench A/B: 128 -> 112.2, 96 -> 113.5, 64 -> 114.5 img/s)
+  const int min_cin = min_cin_arg >= 0 ? min_cin_arg : min_cin_env;      // (the completion launches of the fat schedule: 32 input channels)
   if (!w || cin < min_cin || (cout != 32 && cout != 64) || nsrc < 1 || nsrc > 3) return 0;
   int sum = 0;
   for (int i = 0; i < nsrc; ++i) {
@@ -62,6 +63,25 @@ int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStrea
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
+// the round-occupancy rule of launch_conv_wino, for callers that must know BEFORE they commit to a schedule (fat launches)
+static int wino_ncu() {
+  static int ncu_dev[64] = {0};               // per device (a process may drive several GPUs: nn.DataParallel replicas)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!ncu_dev[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+    ncu_dev[dev] = v;
+  }
+  return ncu_dev[dev];
+}
+bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n) {
+  const int ncu = wino_ncu();
+  const long long nunits = (ntile_n == 2) ? (long long)B * ((W + 31) / 32) * ((H + 7) / 8) : (long long)B * ((W + 31) / 32) * ((H + 15) / 16);
+  const long long rounds = (nunits + ncu - 1) / ncu;
+  return !(rounds >= 2 && nunits * 100 < rounds * ncu * 75) && (long long)B * H * W < (1LL << 24);
+}
+
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) {
   if (!wpack_wino || a.nsrc < 1 || a.nsrc > 3 || a.w2 || a.tC > 0 || a.in_max) return HCF_ERR_UNSUPPORTED;
   wino::Args w;
@@ -81,31 +101,20 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   if (w.ntile_n * 32 != a.out.n) return HCF_ERR_UNSUPPORTED;
   w.bias = a.bias; w.scale = a.scale; w.act = a.act;
   w.out = a.out.p; w.out_cs = a.out.cs; w.out_c0 = a.out.c0; w.cout = a.out.n;
-  if (a.res1.p) { w.res1 = a.res1.p; w.res1_cs = a.res1.cs; w.res1_c0 = a.res1.c0; w.rs1 = a.rs1; }
+  if (a.res1.p && a.res1_pre) { w.pre = a.res1.p; w.pre_cs = a.res1.cs; w.pre_c0 = a.res1.c0; }
+  else if (a.res1.p) { w.res1 = a.res1.p; w.res1_cs = a.res1.cs; w.res1_c0 = a.res1.c0; w.rs1 = a.rs1; }
+  if (a.out2.p) { w.out2 = a.out2.p; w.out2_cs = a.out2.cs; w.out2_c0 = a.out2.c0; w.act2 = a.act_t2; }
   if (a.res2.p) {
-    if (!a.res1.p) return HCF_ERR_UNSUPPORTED;
+    if (!a.res1.p || a.res1_pre) return HCF_ERR_UNSUPPORTED;
     w.res2 = a.res2.p; w.res2_cs = a.res2.cs; w.res2_c0 = a.res2.c0; w.rs2 = a.rs2;
   }
   w.ovf = a.ovf;
   w.zeros = reinterpret_cast<const char*>(a.zeros);
-  static int ncu_dev[64] = {0};               // per device (a process may drive several GPUs: nn.DataParallel replicas)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!ncu_dev[dev]) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
-    ncu_dev[dev] = v;
-  }
-  const int ncu = ncu_dev[dev];
+  const int ncu = wino_ncu();
   // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of
   // config 2, 800 / 1600 units on 256 CUs = 78 / 89 %, measured equal / slightly better here, stays.)
-  {
-    const long long nunits = (w.ntile_n == 2) ? (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8)
-                                              : (long long)a.B * ((a.W + 31) / 32) * ((a.H + 15) / 16);
-    const long long rounds = (nunits + ncu - 1) / ncu;
-    if (rounds >= 2 && nunits * 100 < rounds * ncu * 75) return HCF_ERR_UNSUPPORTED;
-  }
+  if (!conv_wino_rounds_ok(a.B, a.H, a.W, w.ntile_n)) return HCF_ERR_UNSUPPORTED;
   const int r = wino::launch(w, ncu, st, w.ntile_n == 2 ? 4 : 2);      // 64 output channels: the two-tile kernel and its pack layout
   return r == 0 ? HCF_OK : r == -6 ? HCF_ERR_UNSUPPORTED : r == -2 ? HCF_ERR_HIP : HCF_ERR_ARG;
 }

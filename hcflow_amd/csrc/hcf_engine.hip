@@ -70,7 +70,10 @@ struct Step {
   float *mat_invT = nullptr;        // training: (W^-1)^T padded [cmax][cmax] (reverse path: gzc = W^-T gy)
 };
 
-struct Rdb { Conv c[5]; };
+// fat = the "fat launch" form of conv3 / conv4 (profiles/r03_notes.md): c34 = conv3 + the [x, x1, x2] part of conv4 as ONE
+// 64-output-channel Winograd launch (second tile stored raw), c4b = conv4's completion over x3 (adds the stored partial)
+// Pair j = 0: (conv1, conv2), j = 1: (conv3, conv4): ca[j] = conv 2j+1 + the old-input part of conv 2j+2, cb[j] = the completion.
+struct Rdb { Conv c[5]; Conv ca[2], cb[2]; bool fat[2] = {false, false}; };
 struct Rrdb { Rdb r[3]; };
 
 struct CondFlow {
@@ -469,6 +472,34 @@ struct hcf_engine {
     for (int i = 0; i < 4; ++i)
       build_conv(r.c[i], p + ".conv" + std::to_string(i + 1), nf + i * gc, gc, srcs2(nf, i * gc), ACT_LRELU);
     build_conv(r.c[4], p + ".conv5", nf + 4 * gc, nf, srcs2(nf, 4 * gc), ACT_NONE);
+    r.fat[0] = r.fat[1] = false;
+    static const bool no_fat = getenv("HCF_NO_FAT") != nullptr;          // A/B knob, read once
+    if (spec_mode || rc != HCF_OK || !wino_enabled || no_fat || gc != 32 || (nf & 15) || nf < 32) return;
+    for (int j = 0; j < 2 && rc == HCF_OK; ++j) {
+      const std::string pa = p + ".conv" + std::to_string(2 * j + 1), pb = p + ".conv" + std::to_string(2 * j + 2);
+      auto wa = params.find(pa + ".weight"), wb = params.find(pb + ".weight");
+      auto ba = params.find(pa + ".bias"), bb = params.find(pb + ".bias");
+      if (wa == params.end() || wb == params.end() || ba == params.end() || bb == params.end()) return;
+      const int ka = nf + 2 * j * gc, kb = ka + gc;            // input channels of the two convs
+      std::vector<float> wab((size_t)2 * gc * ka * 9), biasab(2 * gc, 0.f), wc((size_t)gc * gc * 9);
+      for (int oc = 0; oc < gc; ++oc) {
+        memcpy(&wab[(size_t)oc * ka * 9], &wa->second.data[(size_t)oc * ka * 9], sizeof(float) * ka * 9);
+        memcpy(&wab[(size_t)(gc + oc) * ka * 9], &wb->second.data[(size_t)oc * kb * 9], sizeof(float) * ka * 9);
+        memcpy(&wc[(size_t)oc * gc * 9], &wb->second.data[((size_t)oc * kb + ka) * 9], sizeof(float) * gc * 9);
+        biasab[oc] = ba->second.data[oc];
+      }
+      pack_conv(r.ca[j], wab.data(), biasab.data(), nullptr, ka, 2 * gc, 3, srcs2(nf, 2 * j * gc), ACT_LRELU);
+      std::vector<int> s1(1, gc);
+      pack_conv(r.cb[j], wc.data(), bb->second.data.data(), nullptr, gc, gc, 3, s1, ACT_LRELU);
+      if (rc == HCF_OK && !r.cb[j].wpack_wino) {         // 32 input channels: below the general Winograd threshold, wanted here
+        std::vector<float> pkw;
+        int one = gc;
+        if (pack_conv_weights_wino(wc.data(), gc, gc, &one, 1, pkw, 16)) r.cb[j].wpack_wino = upload(pkw);
+      }
+      r.ca[j].wkey = pa + ".weight+" + pb + ".weight[:, :" + std::to_string(ka) + "]";
+      r.cb[j].wkey = pb + ".weight[:, " + std::to_string(ka) + ":]";
+      r.fat[j] = rc == HCF_OK && r.ca[j].wpack_wino && r.cb[j].wpack_wino;
+    }
   }
 
   void build_condflow(CondFlow& cf, const std::string& p, int level) {
@@ -576,9 +607,10 @@ struct hcf_engine {
            c2.nsrc == 1 && c2.src_n[0] == 64;
   }
 
+  struct FatExtra { View out2; int act2; bool pre; };        // Winograd-only routing of a fat launch (see Rdb)
   void run_conv(const Conv& cv, std::vector<View> srcs, int H, int W, View out, View res1 = mkview(nullptr, 0, 0, 0),
                 float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f, const Conv* fuse2 = nullptr,
-                const StepArgs* tail = nullptr) {
+                const StepArgs* tail = nullptr, const FatExtra* fat = nullptr) {
     if (rc != HCF_OK) return;
     if ((int)srcs.size() != cv.nsrc) { fail(HCF_ERR_STATE, "internal: conv source count"); return; }
     ConvArgs a;
@@ -593,6 +625,7 @@ struct hcf_engine {
     a.wpack = cv.wpack; a.nchunk = cv.nchunk; a.bias = cv.bias; a.scale = cv.scale; a.act = cv.act;
     a.out = out; a.out.n = cv.cout;
     a.res1 = res1; a.rs1 = rs1; a.res2 = res2; a.rs2 = rs2;
+    if (fat) { a.out2 = fat->out2; a.act_t2 = fat->act2; a.res1_pre = fat->pre ? 1 : 0; }
     if (dry()) return;
     if (prof) {
       if (prof_used == prof_events.size()) {
@@ -626,6 +659,7 @@ struct hcf_engine {
       r = launch_conv_wino(a, cv.wpack_wino, st);      // HCF_ERR_UNSUPPORTED: this call's views do not qualify
       if (r == HCF_OK && prof) prof_events[prof_used].kind = 4;
     }
+    if (fat && r != HCF_OK) { fail(HCF_ERR_STATE, "internal: a fat dense-block launch did not take the Winograd kernel"); return; }
     if (r != HCF_ERR_UNSUPPORTED) {
     } else if (use_f16 && cv.wpack16 && cv.taps == 9) {
       a.wpack = cv.wpack16;
@@ -775,7 +809,7 @@ struct hcf_engine {
   }
 
   struct Scratch {      // per-level temporaries
-    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow;
+    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow, fatp;
   };
 
   // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
@@ -859,8 +893,40 @@ struct hcf_engine {
   }
 
   // ResidualDenseBlock (Basic.py:379-385) with optional second residual (RRDB tail, :394-398)
-  void run_rdb(const Rdb& r, View xin, const Buf& grow, int H, int W, View out, View res2, float rs2) {
+  bool fat_stale = false;        // the fat packs are built from the host weights only (hcf_finalize); a device-side refresh disables them
+  void run_rdb(const Rdb& r, View xin, const Buf& grow, int H, int W, View out, View res2, float rs2, const Buf* fatp = nullptr) {
     const int gc = cfg.rrdb_gc;
+    // Fat pairs (profiles/r03_notes.md): measured per-launch costs say pair (3, 4) pays at every size, pair (1, 2) only where the
+    // launches are short (the 64-channel kernel's fixed cost: 350 + 146 us against 199 + 267 at 16 x 320^2, 82 + 43 against
+    // 61 + 79 at 16 x 160^2) -> below 6 rounds of 32-channel units.
+    const bool fat_ok = fatp && fatp->p && use_f16 && !taping && !fat_stale && !wino_stale && !(g_f16x3_ablation & 256) &&
+                        conv_wino_rounds_ok(B_, H, W, 2) && conv_wino_rounds_ok(B_, H, W, 1);
+    static const int fat12_rounds = getenv("HCF_FAT12_ROUNDS") ? atoi(getenv("HCF_FAT12_ROUNDS")) : 6;      // experiment knob
+    const long long units32 = (long long)B_ * ((W + 31) / 32) * ((H + 15) / 16);
+    const bool use_fat[2] = {fat_ok && r.fat[0] && units32 < (long long)fat12_rounds * 256, fat_ok && r.fat[1]};
+    if (use_fat[0] || use_fat[1]) {
+      const View none = mkview(nullptr, 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        std::vector<View> srcs;
+        srcs.push_back(xin);
+        if (j > 0) srcs.push_back(grow.v(0, 2 * j * gc));
+        if (use_fat[j]) {
+          FatExtra fa = {fatp->v(0, gc), ACT_NONE, false};        // tile 0 -> x_{2j+1} (bias, LeakyReLU), tile 1 -> raw partial of conv 2j+2
+          run_conv(r.ca[j], srcs, H, W, grow.v(2 * j * gc, gc), none, 0.f, none, 0.f, nullptr, nullptr, &fa);
+          FatExtra fb = {none, ACT_NONE, true};                   // x_{2j+2} = lrelu(W[x_{2j+1}] * x_{2j+1} + partial + bias)
+          run_conv(r.cb[j], {grow.v(2 * j * gc, gc)}, H, W, grow.v((2 * j + 1) * gc, gc), fatp->v(0, gc), 0.f, none, 0.f, nullptr,
+                   nullptr, &fb);
+        } else {
+          run_conv(r.c[2 * j], srcs, H, W, grow.v(2 * j * gc, gc));
+          std::vector<View> s2;
+          s2.push_back(xin);
+          s2.push_back(grow.v(0, (2 * j + 1) * gc));
+          run_conv(r.c[2 * j + 1], s2, H, W, grow.v((2 * j + 1) * gc, gc));
+        }
+      }
+      run_conv(r.c[4], {xin, grow.v(0, 4 * gc)}, H, W, out, xin, 0.2f, res2, rs2);
+      return;
+    }
     for (int i = 0; i < 4; ++i) {
       std::vector<View> srcs;
       srcs.push_back(xin);
@@ -873,9 +939,9 @@ struct hcf_engine {
   void run_rrdb(const Rrdb& rr, View x0, View out, int H, int W, Scratch& sc) {
     const int nf = cfg.rrdb_nf;
     const View none = mkview(nullptr, 0, 0, 0);
-    run_rdb(rr.r[0], x0, sc.rgrow, H, W, sc.t1.v(0, nf), none, 0.f);
-    run_rdb(rr.r[1], sc.t1.v(0, nf), sc.rgrow, H, W, sc.t2.v(0, nf), none, 0.f);
-    run_rdb(rr.r[2], sc.t2.v(0, nf), sc.rgrow, H, W, out, x0, 0.2f);
+    run_rdb(rr.r[0], x0, sc.rgrow, H, W, sc.t1.v(0, nf), none, 0.f, &sc.fatp);
+    run_rdb(rr.r[1], sc.t1.v(0, nf), sc.rgrow, H, W, sc.t2.v(0, nf), none, 0.f, &sc.fatp);
+    run_rdb(rr.r[2], sc.t2.v(0, nf), sc.rgrow, H, W, out, x0, 0.2f, &sc.fatp);
   }
 
   // ConditionalFlow.get_conditional_feature_SR / _Rescaling (ConditionalFlow.py:99-110) -> cfbuf
@@ -894,7 +960,7 @@ struct hcf_engine {
         for (const View& v : u) ub.push_back(shiftv(v, b0));
         Scratch sb = sc;
         sb.t1 = shiftb(sc.t1, b0); sb.t2 = shiftb(sc.t2, b0); sb.x = shiftb(sc.x, b0); sb.f0 = shiftb(sc.f0, b0);
-        sb.rgrow = shiftb(sc.rgrow, b0);
+        sb.rgrow = shiftb(sc.rgrow, b0); sb.fatp = shiftb(sc.fatp, b0);
         run_cond_features_all(cf, ub, H, W, shiftb(cfbuf, b0), sb);
       }
       B_ = Bfull;
@@ -948,6 +1014,7 @@ struct hcf_engine {
     sc.x = alloc(B_, H, W, nf);
     sc.f0 = alloc(B_, H, W, nf);
     sc.rgrow = alloc(B_, H, W, 4 * cfg.rrdb_gc);
+    sc.fatp = alloc(B_, H, W, cfg.rrdb_gc);          // stored partial sum of the fat dense-block launches
     return sc;
   }
 
@@ -1343,6 +1410,7 @@ int hcf_finalize(hcf_engine* e, int device) {
   e->invalidate_tapes();
   e->host_stale = false;
   e->wino_stale = false;       // build() re-packs the Winograd form from the host weights
+  e->fat_stale = false;
   e->device = device;
   e->spec_mode = false;
   e->rc = HCF_OK;
