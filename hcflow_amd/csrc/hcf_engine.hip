@@ -898,12 +898,12 @@ struct hcf_engine {
     const int gc = cfg.rrdb_gc;
     // Fat pairs (profiles/r03_notes.md): measured per-launch costs say pair (3, 4) pays at every size, pair (1, 2) only where the
     // launches are short (the 64-channel kernel's fixed cost: 350 + 146 us against 199 + 267 at 16 x 320^2, 82 + 43 against
-    // 61 + 79 at 16 x 160^2) -> below 6 rounds of 32-channel units.
+    // 61 + 79 at 16 x 160^2) -> up to 200 x 200 pixels per sample. The rule looks at the SAMPLE size, not at the batch: a sample's
+    // bits must not depend on how many others share its launch (tests/test_gpu_nets.py: batch independence).
     const bool fat_ok = fatp && fatp->p && use_f16 && !taping && !fat_stale && !wino_stale && !(g_f16x3_ablation & 256) &&
                         conv_wino_rounds_ok(B_, H, W, 2) && conv_wino_rounds_ok(B_, H, W, 1);
-    static const int fat12_rounds = getenv("HCF_FAT12_ROUNDS") ? atoi(getenv("HCF_FAT12_ROUNDS")) : 6;      // experiment knob
-    const long long units32 = (long long)B_ * ((W + 31) / 32) * ((H + 15) / 16);
-    const bool use_fat[2] = {fat_ok && r.fat[0] && units32 < (long long)fat12_rounds * 256, fat_ok && r.fat[1]};
+    static const long long fat12_pixels = getenv("HCF_FAT12_PIXELS") ? atoll(getenv("HCF_FAT12_PIXELS")) : 40000;   // experiment knob
+    const bool use_fat[2] = {fat_ok && r.fat[0] && (long long)H * W <= fat12_pixels, fat_ok && r.fat[1]};
     if (use_fat[0] || use_fat[1]) {
       const View none = mkview(nullptr, 0, 0, 0);
       for (int j = 0; j < 2; ++j) {
