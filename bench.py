@@ -53,6 +53,8 @@ VARIANTS = {
               ("hcf::wino::conv_wino2_kernel<0|3> Winograd F(2x2,3x3) form, 32 out-ch: RDB conv1 / conv2 and the 32 -> 32 completions of "
                "the fat launches", 9, 1, 4, ["wino<0>", "wino<3>"]),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,*,true,0,8,false> FCN conv1 3x3 + conv2 1x1 (FUSE2)", 9, 2, 1, ["f16x3<2>+fuse2"]),
+              ("hcf::wino::conv_wino4_kernel<3> conditional FCN conv1 (Winograd, [z1 padded to 16 | 128 features] -> 64) + conv2 1x1 in "
+               "its epilogue", 9, 2, 6, ["wino4<3>"]),
               ("hcf::fcn12::fcn12_kernel<false> FCN conv1 3x3 (<= 16 in-ch) + conv2 1x1, persistent, weights in registers", 9, 2, 5, ["fcn12"]),
               ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2, []),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,true,false,0,8,false> conv_first on upsampled LR (UP)", 9, 2, 3, ["f16x3<2>+up"]),

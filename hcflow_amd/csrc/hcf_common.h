@@ -58,6 +58,7 @@ struct ConvArgs {
   const float* bias2; const float* scale2; int act2;
   // f16x3 kernel, optional fused inverse flow-step tail (tC > 0): z <- actnorm^-1(W^-1 coupling^-1(z, h = this conv))
   View tz; View tzo; const float* tmat; const float* tbias; const float* tmul; int tC, tns, tmode;
+  float* tzpad; int tzpad_n;       // ... and StepArgs::zpad16 / zpad_n
   const float* zeros;      // f16x3 kernel: >= 64 bytes of zeros in device memory (out-of-image halo reads)
   const float* in_max;     // f16x3 kernel, optional (training): device float = max |x| of source 0 -> power-of-two input scaling
   unsigned long long* dbg; // HCF_CONV_TIMERS builds only (tools/conv_bench.py): phase timers of a few mid-grid blocks
@@ -65,6 +66,9 @@ struct ConvArgs {
   // Winograd kernels only ("fat" dense-block launches, hcf_engine.hip run_rdb): out2.p != null -> output channels [32, 64) go to
   // out2 with activation act_t2 instead of `out`; res1_pre != 0 -> res1 is a stored partial sum added BEFORE bias / activation
   View out2; int act_t2; int res1_pre;
+  // 64-channel Winograd kernel only: the 1x1 second layer of an FCN coupling net in its epilogue (hcf_conv_wino.h Args::f_w);
+  // wf1x1 = wino::pack_weights_1x1_frag of the 64 x 64 weights, bias2 / scale2 / act2 as for the fused f16x3 form
+  const void* wf1x1;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -88,6 +92,7 @@ int launch_fcn12(const ConvArgs& a, hipStream_t st);
 // Winograd F(2x2,3x3) form of the same f16x3 conv (hcf_conv_wino.hip): eligible layers only (pack size 0 otherwise);
 // HCF_ERR_UNSUPPORTED when the call cannot take it (upsampled source, unaligned views, > 2^24 pixels): use the direct kernel
 size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out, int min_cin = -1);
+size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st);   // pack rebuilt from device weights
@@ -152,6 +157,7 @@ struct StepArgs {
   float* partial;        // forward couple: per-block partial sums of logscale, [B][nblk]; else nullptr
   int partial_stride;    // floats between consecutive samples in `partial`
   View aux;              // forward head, training tape: also store the ActNorm output (input of W); p == nullptr: no
+  float* zpad16; int zpad_n;   // inverse tail: also store out[:, :zpad_n] as a zero-padded 16-channel tensor (or nullptr)
 };
 
 int launch_step_tail_inv(const StepArgs& a, hipStream_t st);     // coupling^-1, W^-1, actnorm^-1
@@ -274,6 +280,7 @@ int launch_unsqueeze_nchw(View in, float* dst, int B, int C4, int H, int W, int 
 int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t st);
 int launch_haar_inv(View in, View out, int B, int C4, int H, int W, hipStream_t st);
 int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st);
+int launch_copy_pad16(View in, float* out16, int B, int H, int W, hipStream_t st);   // [B, H, W, 16]: channels of `in` (<= 16), then zeros
 // SR forward tail: zq = round(clamp(z,0,1)*255)/255 ; lr_hat NCHW = zq ; partial += logp(lr; mean zq, logs -6)
 int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W,
                       float* partial, int partial_stride, hipStream_t st);

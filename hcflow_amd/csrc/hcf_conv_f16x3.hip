@@ -464,6 +464,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
       step_tail_inverse_pixel<TAILC>(z, hl + tid * HCS, a.tC, a.tns, a.tmode, a.tmat, a.tbias, a.tmul, yv);
       store_pixel<TAILC>(a.tzo, pix, a.tC, yv);
+      if (a.tzpad) store_pad16<TAILC>(a.tzpad, pix, a.tzpad_n, yv);
     }
     return;
   }

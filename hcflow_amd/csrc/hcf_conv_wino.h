@@ -64,6 +64,11 @@ struct Args {
   // may add a stored partial sum BEFORE bias / activation (conv k+1's completion): pre != null -> res1 / res2 are unused.
   float* out2; int out2_cs, out2_c0, act2;                  // 64-channel kernel only; null: both tiles go to `out`
   const float* pre; int pre_cs, pre_c0;                     // 32-channel kernel only
+  // fused 1x1 second layer (FCN conv1 -> conv2 of the conditional coupling nets, Basic.py:441-447; hcf_engine.hip
+  // run_coupling_net): 64-channel kernel only. The first layer's tile (after bias / scale / activation) is split and parked in
+  // LDS as the B operand of a 64 x 64 product: out = act_f((W_f h1 + f_bias) * f_scale); res1 / res2 / out2 are unused.
+  const char* f_w;                                          // pack_weights_1x1_frag: 16 KB
+  const float* f_bias; const float* f_scale; int f_act;
   int* ovf;
   const char* zeros;       // >= 64 bytes of zeros
   unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
@@ -133,6 +138,28 @@ static inline bool pack_weights_wino64(const float* w, int cin, int cout, std::v
   return true;
 }
 
+// 1x1 64 -> 64 layer fused into the 64-channel kernel's epilogue: the A fragments of v_mfma_f32_32x32x16_f16 in lane order,
+// piece ((m-tile * 4 + k-step) * 2 + plane) = [64 lanes][8 halves], lane (half, li) = output channel 32 mt + li, input channels
+// 16 s + 8 half .. + 7; planes as everywhere: f16(w) * 2^11 and f16((w - f16(w)) * 2^11). w: [64][64] (PyTorch [cout][cin][1][1]).
+constexpr int F1_BYTES = 16384;
+static inline bool pack_weights_1x1_frag(const float* w, std::vector<uint16_t>& pk) {
+  pk.assign(F1_BYTES / 2, 0);
+  for (int mt = 0; mt < 2; ++mt)
+    for (int ks = 0; ks < 4; ++ks)
+      for (int ln = 0; ln < 64; ++ln)
+        for (int e = 0; e < 8; ++e) {
+          const int oc = mt * 32 + (ln & 31), ic = 16 * ks + 8 * (ln >> 5) + e;
+          const float x = w[oc * 64 + ic];
+          if (!(fabsf(x) * 2048.f < 60000.f)) return false;
+          const _Float16 hi = (_Float16)x;
+          const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((x - (float)hi) * 2048.f);
+          const size_t o = ((size_t)((mt * 4 + ks) * 2 + 0) * 64 + ln) * 8 + e;
+          memcpy(&pk[o], &p0, 2);
+          memcpy(&pk[o + 512], &p1, 2);
+        }
+  return true;
+}
+
 #if defined(__HIPCC__)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -194,6 +221,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& h, u32x4& l) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const f16x2 hh = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+    h[i] = __builtin_bit_cast(uint32_t, hh);
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h[i]), "v"(v[2 * i]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h[i]), "v"(v[2 * i + 1]));
+    l[i] = lo;
+  }
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const f32x4& v, u32x2& h, u32x2& l) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
     const f16x2 hh = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
     h[i] = __builtin_bit_cast(uint32_t, hh);
     uint32_t lo;
@@ -535,7 +575,7 @@ constexpr int TH4 = 8, HH4 = TH4 + 2;
 constexpr int A4_BYTES = 22 * 1024;               // 1 360 real pieces (10 x 34 pixels x 4 parts) + 48 dead
 constexpr int W4_OFF = A4_BYTES;                  // two weight buffers of W4_BYTES
 constexpr int TAB4_OFF = A4_BYTES + 2 * W4_BYTES; // 153 600
-constexpr int LDS4_BYTES = TAB4_OFF + 512;        // 154 112
+constexpr int LDS4_BYTES = TAB4_OFF + 1024;       // 154 624 (tables: bias, scale of the conv and of the fused 1x1 layer)
 constexpr int NPIECE4 = 22 + 64;                  // DMA instructions per chunk
 }  // namespace v4
 
@@ -644,9 +684,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   const int offA = rA * ROWB, offB = rB * ROWB;
   const int fw = half * 512 + li * 16 + xi * (4 * 4 * 1024);      // + ((nu * 2 + ntile) * 2 + plane) * 1024
 
+  constexpr bool F1 = (RES == 3);                // fused 1x1 second layer (Args::f_w)
   if (tid < 64) {
     reinterpret_cast<float*>(lds + TAB4_OFF)[tid] = a.bias[tid] * a.scale[tid];
     reinterpret_cast<float*>(lds + TAB4_OFF)[64 + tid] = a.scale[tid] * UNSPLIT;
+    if (F1) {
+      reinterpret_cast<float*>(lds + TAB4_OFF)[128 + tid] = a.f_bias[tid] * a.f_scale[tid];
+      reinterpret_cast<float*>(lds + TAB4_OFF)[192 + tid] = a.f_scale[tid] * UNSPLIT;
+    }
   }
   int u = blockIdx.x;
   if (u >= nunits) return;
@@ -662,6 +707,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   int g = 0;
   const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
   const float slope2 = a.act2 == 1 ? 0.f : a.act2 == 2 ? 0.2f : 1.f;
+  const float slope_f = a.f_act == 1 ? 0.f : a.f_act == 2 ? 0.2f : 1.f;
 
   while (true) {
     f32x16 acc[4][2];
@@ -768,6 +814,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
     const int wpos = (half * 32 + ((li + 4 * half) & 31)) * 16;                 // writer slot for even q; odd q: + 8 patches (mod 32)
     const int wpos1 = (half * 32 + ((li + 4 * half + 8) & 31)) * 16;
     const int rpos = (hd * 32 + ((patch + 4 * hd + 8 * (qd & 1)) & 31)) * 16 + qd * 1024;
+    f32x4 hv[2][2][2];                              // F1: the first layer's values of this lane (2 rounds x 2 x 2 pixels x 4 channels)
     __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
 #if defined(WINO_PROF)
     pw[7] += __builtin_readcyclecounter() - qe0;    // (skew of the chunk loop: wait for the slowest wave)
@@ -785,7 +832,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
           const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
           oks[oa][ob] = yy < H && xx < W;
           pixs[oa][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
-          if (RES >= 1) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[oa][ob] * a.res1_cs + a.res1_c0 + cb);
+          if (RES == 1 || RES == 2) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[oa][ob] * a.res1_cs + a.res1_c0 + cb);
           if (RES == 2) rv2[oa][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[oa][ob] * a.res2_cs + a.res2_c0 + cb);
         }
       if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's buffer has been read
@@ -823,14 +870,85 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
             chk = fmaf(yv, 0.f, chk);
             const float z = fmaf(yv, ms[e], bs[e]);
             v[e] = fmaxf(z, slope_t * z);
-            if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
+            if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
             if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
           }
-          if (oks[oa][ob] && cb < a.cout) {
+          if (F1) hv[nt][oa][ob] = v;
+          else if (oks[oa][ob] && cb < a.cout) {
             if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pixs[oa][ob] * a.out2_cs + a.out2_c0 + (cb - 32)) = v;
             else *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
           }
         }
+    }
+    if (F1) {
+      // ---- second layer: h2 = act_f((W_f h1 + bias_f) * scale_f) on the tile's 256 pixels. The exchange buffer becomes 256 pixel
+      // records of 256 bytes: 16 slots of 8 halves, slot (plane * 8 + channel / 8) ^ (pixel & 15) (a 128-bit LDS read is served in
+      // groups of 16 lanes, here 16 consecutive pixels -> 16 distinct slots). A wave multiplies 32 pixels (the N of
+      // the matrix instruction) of two tile rows by one 32-channel half of W_f; its A fragments come from L2 (8 KB, lane order).
+      const int mt = wave & 1, r0 = 2 * (wave >> 1);    // this wave: output channels 32 mt .. + 31 of tile rows r0, r0 + 1
+      f16x8 wf[4][2];
+      asm volatile("" ::: "memory");                // (keeps the fragments' registers out of the exchange rounds' live range)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          wf[ks][pl] = *reinterpret_cast<const f16x8*>(a.f_w + (size_t)(((mt * 4 + ks) * 2 + pl) * 64 + lane) * 16);
+      char* const rec = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES;
+      __builtin_amdgcn_s_barrier();                 // round 1's exchange has been read by every wave
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+          for (int ob = 0; ob < 2; ++ob) {
+            const int pi_ = (4 * tg + 2 * prow + oa) * 32 + 2 * pcol + ob;
+            u32x2 h_, l_;
+            split4(hv[nt][oa][ob], h_, l_);
+            char* const rp = rec + pi_ * 256 + hd * 8;
+            *reinterpret_cast<u32x2*>(rp + (((nt * 4 + qd) ^ (pi_ & 15)) << 4)) = h_;
+            *reinterpret_cast<u32x2*>(rp + (((8 + nt * 4 + qd) ^ (pi_ & 15)) << 4)) = l_;
+          }
+      __builtin_amdgcn_s_barrier();
+      f32x16 c2[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c2[rr][r] = 0.f;
+      const char* const rq = rec + (r0 * 32 + li) * 256;
+      const int key = li & 15;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const f16x8 vh_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((2 * ks + half) ^ key) << 4));
+          const f16x8 vl_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((8 + 2 * ks + half) ^ key) << 4));
+          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vh_, c2[rr], 0, 0, 0);
+          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], vh_, c2[rr], 0, 0, 0);
+          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vl_, c2[rr], 0, 0, 0);
+        }
+      }
+      const int xx = ex0 + li;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int yy = ey0 + r0 + rr;
+        const bool ok2 = yy < H && xx < W;
+        float* const op = a.out + ((size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (size_t)(xx < W ? xx : W - 1)) * a.out_cs + a.out_c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cb2 = mt * 32 + 8 * q + 4 * half;
+          const f32x4 bs2 = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 512 + cb2 * 4);
+          const f32x4 ms2 = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 768 + cb2 * 4);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yv = c2[rr][4 * q + e];
+            chk = fmaf(yv, 0.f, chk);
+            const float z = fmaf(yv, ms2[e], bs2[e]);
+            v[e] = fmaxf(z, slope_f * z);
+          }
+          if (ok2) *reinterpret_cast<f32x4*>(op + cb2) = v;
+        }
+      }
     }
     if (__any(chk != chk)) {
       if (lane == 0) atomicOr(a.ovf, 1);
@@ -884,7 +1002,8 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   bool (&attr)[3][4] = attr_dev[dev_];
   if (a.pre && (version != 2 || a.res1 || a.res2 || ((a.pre_cs | a.pre_c0) & 3) || (reinterpret_cast<uintptr_t>(a.pre) & 15))) return -6;
   if (a.out2 && (version != 4 || a.res1 || ((a.out2_cs | a.out2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out2) & 15))) return -6;
-  const int res = a.pre ? 3 : a.res2 ? 2 : a.res1 ? 1 : 0;
+  if (a.f_w && (version != 4 || a.res1 || a.res2 || a.out2 || !a.f_bias || !a.f_scale || (reinterpret_cast<uintptr_t>(a.f_w) & 15))) return -6;
+  const int res = (a.pre || a.f_w) ? 3 : a.res2 ? 2 : a.res1 ? 1 : 0;
   const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
   const int vi = (version == 2) ? 1 : (version == 4) ? 2 : 0;
   auto go = [&](auto fn, int threads) {
@@ -898,6 +1017,7 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (version == 4) {
     if (res == 0) return go(conv_wino4_kernel<0>, 512);
     if (res == 1) return go(conv_wino4_kernel<1>, 512);
+    if (res == 3) return go(conv_wino4_kernel<3>, 512);
     return go(conv_wino4_kernel<2>, 512);
   }
   if (version == 2) {

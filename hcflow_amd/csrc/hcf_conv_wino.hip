@@ -27,6 +27,16 @@ size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs
   return pk.size() * 2;
 }
 
+// lane-order pack of a 1x1 64 -> 64 layer for the fused epilogue of the 64-channel kernel (w: [64][64]); 0 = not representable
+size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out) {
+  out.clear();
+  std::vector<uint16_t> pk;
+  if (!w || !wino::pack_weights_1x1_frag(w, pk)) return 0;
+  out.resize(pk.size() / 2);
+  memcpy(out.data(), pk.data(), pk.size() * 2);
+  return pk.size() * 2;
+}
+
 // Device-side rebuild of a Winograd pack from the PyTorch-layout weight in device memory (after an optimiser step): the same
 // arithmetic as wino::pack_weights_wino, one thread per (output channel, input channel).
 __global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, uint16_t* __restrict__ pk) {
@@ -103,6 +113,10 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   w.out = a.out.p; w.out_cs = a.out.cs; w.out_c0 = a.out.c0; w.cout = a.out.n;
   if (a.res1.p && a.res1_pre) { w.pre = a.res1.p; w.pre_cs = a.res1.cs; w.pre_c0 = a.res1.c0; }
   else if (a.res1.p) { w.res1 = a.res1.p; w.res1_cs = a.res1.cs; w.res1_c0 = a.res1.c0; w.rs1 = a.rs1; }
+  if (a.wf1x1) {
+    if (a.res1.p || a.res2.p || a.out2.p || !a.bias2 || !a.scale2) return HCF_ERR_UNSUPPORTED;
+    w.f_w = reinterpret_cast<const char*>(a.wf1x1); w.f_bias = a.bias2; w.f_scale = a.scale2; w.f_act = a.act2;
+  }
   if (a.out2.p) { w.out2 = a.out2.p; w.out2_cs = a.out2.cs; w.out2_c0 = a.out2.c0; w.act2 = a.act_t2; }
   if (a.res2.p) {
     if (!a.res1.p || a.res1_pre) return HCF_ERR_UNSUPPORTED;

@@ -39,7 +39,7 @@ struct Spec {
 };
 
 // One fused conv layer, packed for conv_mfma_kernel
-extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip (hcf_debug_set_ablation; bit 256: no Winograd kernels)
+extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip (hcf_debug_set_ablation; bit 256: no Winograd kernels, bit 512: no Winograd form of FCN conv1 + conv2)
 
 struct Conv {
   int taps = 9, cout = 0, nsrc = 0, src_n[kMaxSrc] = {0, 0, 0}, nchunk = 0, npad = 0, act = ACT_NONE;
@@ -65,6 +65,10 @@ struct Step {
   double lad = 0;                   // slogdet(W) alone
   std::string an_key;               // prefix of the step's ActNorm ("....actnorm")
   std::string wkey;                 // "....permute.weight" (or "")
+  // conditional FCN coupling nets, f16x3 inference: conv1 as a 64-channel Winograd launch over [z1 padded to 16 | features] with
+  // conv2 (1x1) in its epilogue (profiles/r03_notes.md section 8). c1w = c[0] with that source list and pack; built by finalize.
+  Conv c1w;
+  float* w4f_frag = nullptr;
   float *mat_fwdT = nullptr;        // training: W^T padded [cmax][cmax] (gza = W^T gzb)
   float *winvT = nullptr;           // training: W^-T, [C][C] unpadded (d slogdet / dW)
   float *mat_invT = nullptr;        // training: (W^-1)^T padded [cmax][cmax] (reverse path: gzc = W^-T gy)
@@ -411,6 +415,28 @@ struct hcf_engine {
       build_conv_an(s.c[0], f + ".conv1", s.f_in, hid, 3, srcs2(z1_n, cond));
       build_conv_an(s.c[1], f + ".conv2", hid, hid, 1, srcs2(hid, 0));
       build_conv_zeros(s.c[2], f + ".conv3", hid, s.f_out, srcs2(hid, 0));
+      s.c1w = Conv();
+      s.w4f_frag = nullptr;
+      static const bool no_w4f = getenv("HCF_NO_W4F") != nullptr;      // A/B knob, read once
+      if (!spec_mode && rc == HCF_OK && wino_enabled && !no_w4f && cond >= 16 && (cond & 15) == 0 && z1_n <= 16 && hid == 64 &&
+          s.c[0].wpack16 && s.c[1].wpack16) {
+        const std::vector<float>& w1 = params[f + ".conv1.weight"].data;
+        const std::vector<float>& w2 = params[f + ".conv2.weight"].data;
+        const int cin_p = 16 + cond;
+        std::vector<float> wp((size_t)hid * cin_p * 9, 0.f), pk, fr;
+        for (int oc = 0; oc < hid; ++oc)
+          for (int ic = 0; ic < s.f_in; ++ic)
+            memcpy(&wp[((size_t)oc * cin_p + (ic < z1_n ? ic : ic - z1_n + 16)) * 9], &w1[((size_t)oc * s.f_in + ic) * 9], 9 * sizeof(float));
+        const int sp[2] = {16, cond};
+        if (w1.size() == (size_t)hid * s.f_in * 9 && w2.size() == (size_t)hid * hid &&
+            pack_conv_weights_wino(wp.data(), cin_p, hid, sp, 2, pk, 16) && pack_conv_weights_1x1_frag(w2.data(), fr)) {
+          s.c1w = s.c[0];
+          s.c1w.src_n[0] = 16;
+          s.c1w.wpack_wino = upload(pk);
+          s.c1w.tpacks.clear();
+          s.w4f_frag = upload(fr);
+        }
+      }
     } else {
       // DenseBlock(in, out, gc=hid) (Basic.py:329-356); dense concat order is (x, x1, x2, ...) and x itself
       // is cat(z1, u) when conditional -> sources: z1 [, u], growth
@@ -607,7 +633,7 @@ struct hcf_engine {
            c2.nsrc == 1 && c2.src_n[0] == 64;
   }
 
-  struct FatExtra { View out2; int act2; bool pre; };        // Winograd-only routing of a fat launch (see Rdb)
+  struct FatExtra { View out2; int act2; bool pre; const float* w4f_frag; };   // Winograd-only routing: fat launches (see Rdb), fused 1x1 layer (Step::c1w)
   void run_conv(const Conv& cv, std::vector<View> srcs, int H, int W, View out, View res1 = mkview(nullptr, 0, 0, 0),
                 float rs1 = 0.f, View res2 = mkview(nullptr, 0, 0, 0), float rs2 = 0.f, const Conv* fuse2 = nullptr,
                 const StepArgs* tail = nullptr, const FatExtra* fat = nullptr) {
@@ -653,11 +679,13 @@ struct hcf_engine {
     ++launch_seq;
     if (probe_on) probe_conv(cv, srcs, H, W);
     int r = HCF_ERR_UNSUPPORTED;
-    if (use_f16 && cv.wpack_wino && !fuse2 && !tail && !wino_stale && !(g_f16x3_ablation & 256)) {
+    const bool w4f = fat && fat->w4f_frag && fuse2;    // Winograd conv1 + the 1x1 layer in its epilogue
+    if (use_f16 && cv.wpack_wino && (!fuse2 || w4f) && !tail && !wino_stale && !(g_f16x3_ablation & 256)) {
       a.ovf = ovf_flag;
       a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
+      if (w4f) { a.wf1x1 = fat->w4f_frag; a.bias2 = fuse2->bias; a.scale2 = fuse2->scale; a.act2 = fuse2->act; }
       r = launch_conv_wino(a, cv.wpack_wino, st);      // HCF_ERR_UNSUPPORTED: this call's views do not qualify
-      if (r == HCF_OK && prof) prof_events[prof_used].kind = 4;
+      if (r == HCF_OK && prof) prof_events[prof_used].kind = w4f ? 6 : 4;
     }
     if (fat && r != HCF_OK) { fail(HCF_ERR_STATE, "internal: a fat dense-block launch did not take the Winograd kernel"); return; }
     if (r != HCF_ERR_UNSUPPORTED) {
@@ -671,6 +699,7 @@ struct hcf_engine {
       if (tail) {
         a.tz = tail->z; a.tzo = tail->out; a.tmat = tail->mat; a.tbias = tail->an_bias; a.tmul = tail->an_mul;
         a.tC = tail->C; a.tns = tail->ns; a.tmode = tail->mode;
+        a.tzpad = tail->zpad16; a.tzpad_n = tail->zpad_n;
       }
       r = HCF_ERR_UNSUPPORTED;
       if (fuse2 && !tail) {                 // one K chunk: the persistent small-K form (res1 = pre-activation term, if any)
@@ -809,7 +838,7 @@ struct hcf_engine {
   }
 
   struct Scratch {      // per-level temporaries
-    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow, fatp;
+    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow, fatp, zpad;
   };
 
   // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
@@ -822,6 +851,13 @@ struct hcf_engine {
     return use_f16 && s.fcn && c.wpack16 && c.taps == 9 && s.f_out <= 32 && s.cmax <= 24;   // the 48-channel variant spills
   }
 
+  // conditional FCN coupling net as Winograd conv1 + 1x1 conv2 in its epilogue (Step::c1w)?
+  bool zpad_valid = false;       // sc.zpad already holds the coming step's z1 (written by the tail of the step before)
+  bool w4f_ok(const Step& s, const View* u, int H, int W, const Scratch& sc) const {
+    return s.fcn && s.w4f_frag && s.cond > 0 && u && s.mode == CPL_AFFINE && can_fuse_fcn(s.c[0], s.c[1]) && !fat_stale && !wino_stale &&
+           !(g_f16x3_ablation & (256 | 512)) && u->up == 0 && sc.zpad.p && conv_wino_rounds_ok(B_, H, W, 2);
+  }
+
   void run_coupling_net(const Step& s, View z1, const View* u, int H, int W, Scratch& sc, const StepArgs* tail = nullptr) {
     std::vector<View> in;
     in.push_back(z1);
@@ -830,7 +866,14 @@ struct hcf_engine {
       in.push_back(*u);
     }
     if (s.fcn) {
-      if (can_fuse_fcn(s.c[0], s.c[1])) {
+      if (w4f_ok(s, u, H, W, sc)) {
+        // conv1 on the Winograd kernel (sources: z1 padded to one 16-channel chunk, the features), conv2 in its epilogue
+        const View none = mkview(nullptr, 0, 0, 0);
+        if (!zpad_valid) HCF_LAUNCH(launch_copy_pad16(z1, sc.zpad.p, B_, H, W, st));    // (else: the previous step's tail wrote it)
+        zpad_valid = false;
+        const FatExtra fx = {none, ACT_NONE, false, s.w4f_frag};
+        run_conv(s.c1w, {sc.zpad.v(0, 16), *u}, H, W, sc.h2.v(0, s.hid), none, 0.f, none, 0.f, &s.c[1], nullptr, &fx);
+      } else if (can_fuse_fcn(s.c[0], s.c[1])) {
         const View none = mkview(nullptr, 0, 0, 0);
         run_conv(s.c[0], in, H, W, sc.h2.v(0, s.hid), none, 0.f, none, 0.f, &s.c[1]);
       } else {
@@ -857,18 +900,23 @@ struct hcf_engine {
   }
 
   // FlowStep.reverse_flow (FlowStep.py:53-64), in place on z
-  void run_step_inverse(const Step& s, const Buf& z, const View* u, int H, int W, Scratch& sc) {
+  // `next` = the step that runs after this one on the same z (or null): when it takes the Winograd form of its FCN, this
+  // step's tail also writes next's z1 as the padded 16-channel tensor that form reads (saves a copy launch per step)
+  void run_step_inverse(const Step& s, const Buf& z, const View* u, int H, int W, Scratch& sc, const Step* next = nullptr) {
     StepArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B_; a.H = H; a.W = W; a.C = s.C; a.ns = s.ns; a.mode = s.mode;
     a.z = z.all(); a.h = sc.hout.v(0, s.f_out); a.out = z.all();
     a.mat = s.has_mat ? s.mat_inv : nullptr; a.an_bias = s.bias; a.an_mul = s.mul_inv;
+    const bool pad_next = next && next->C == s.C && w4f_ok(*next, u, H, W, sc);
+    if (pad_next) { a.zpad16 = sc.zpad.p; a.zpad_n = next->ns; }
     if (can_fuse_tail(s)) {
       run_coupling_net(s, step_z1(s, z), u, H, W, sc, &a);      // conv3's epilogue finishes the step
-      return;
+    } else {
+      run_coupling_net(s, step_z1(s, z), u, H, W, sc);
+      HCF_LAUNCH(launch_step_tail_inv(a, st));
     }
-    run_coupling_net(s, step_z1(s, z), u, H, W, sc);
-    HCF_LAUNCH(launch_step_tail_inv(a, st));
+    zpad_valid = pad_next && !dry() && rc == HCF_OK;
   }
 
   // FlowStep.normal_flow (FlowStep.py:40-51), in place on z; partial slot advanced when `partial`
@@ -1015,6 +1063,7 @@ struct hcf_engine {
     sc.f0 = alloc(B_, H, W, nf);
     sc.rgrow = alloc(B_, H, W, 4 * cfg.rrdb_gc);
     sc.fatp = alloc(B_, H, W, cfg.rrdb_gc);          // stored partial sum of the fat dense-block launches
+    sc.zpad = alloc(B_, H, W, 16);                   // z1 of a conditional coupling net, zero padded (Step::c1w)
     return sc;
   }
 
@@ -1094,7 +1143,9 @@ struct hcf_engine {
         g.out = a.all();
         HCF_LAUNCH(launch_gauss_sample(g, st));
       }
-      for (int k = (int)cf.steps.size() - 1; k >= 0; --k) run_step_inverse(cf.steps[k], a, &cfv, H, W, sc);
+      zpad_valid = false;
+      for (int k = (int)cf.steps.size() - 1; k >= 0; --k) run_step_inverse(cf.steps[k], a, &cfv, H, W, sc, k > 0 ? &cf.steps[k - 1] : nullptr);
+      zpad_valid = false;
       // Split reverse: z = cat(z, a)   (Basic.py:498-499)
       HCF_LAUNCH(launch_copy_view(a.all(), z.v(lv.ns, cf.Ca), B, H, W, st));
       for (int k = (int)lv.steps.size() - 1; k >= 0; --k) run_step_inverse(lv.steps[k], z, nullptr, H, W, sc);

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
   step_tail_inverse_pixel<CMAX>(z, hp, a.C, a.ns, a.mode, a.mat, a.an_bias, a.an_mul, y);
   if (a.aux.p) store_pixel<CMAX>(a.aux, pix, a.C, z);          // training tape: z after coupling^-1 (input of W^-1)
   store_pixel<CMAX>(a.out, pix, a.C, y);
+  if (a.zpad16) store_pad16<CMAX>(a.zpad16, pix, a.zpad_n, y);
 }
 
 // ---- forward flow step head: actnorm -> W  (FlowStep.py:40-47) --------------------------------
@@ -362,6 +363,21 @@ __global__ __launch_bounds__(256) void copy_view_kernel(View in, View out, int h
   for (int c = 0; c < in.n; ++c) op[c] = ip[c];
 }
 
+// z1 of a conditional coupling net as a 16-channel tensor of its own (zero padded): the first source of the Winograd form of
+// FCN conv1, whose sources are whole 16-channel chunks (hcf_engine.hip run_coupling_net)
+__global__ __launch_bounds__(256) void copy_pad16_kernel(View in, float* __restrict__ out16, int hw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const size_t pix = (size_t)blockIdx.y * hw + i;
+  const float* ip = in.p + pix * in.cs + in.c0;
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = c < in.n ? ip[c] : 0.f;
+  float4* op = reinterpret_cast<float4*>(out16 + pix * 16);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) op[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
 // Quant (Basic.py:187-191) + logp(lr, logs=-6, zq) (HCFlowNet_SR_arch.py:58-63); z has 3 channels
 __global__ __launch_bounds__(256) void quant_logp_kernel(View z, const float* lr, float* lr_hat, int C, int hw,
                                                         float* partial, int partial_stride) {
@@ -510,6 +526,11 @@ int launch_unsqueeze_nchw(View in, float* dst, int B, int C4, int H, int W, int 
 }
 int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(copy_view_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, H * W);
+  HCF_RET();
+}
+int launch_copy_pad16(View in, float* out16, int B, int H, int W, hipStream_t st) {
+  if (in.n < 1 || in.n > 16 || !out16) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(copy_pad16_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out16, H * W);
   HCF_RET();
 }
 int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W, float* partial,

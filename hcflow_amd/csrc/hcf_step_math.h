@@ -53,6 +53,20 @@ __device__ __forceinline__ void store_pixel(const View& v, size_t pix, int C, co
   }
 }
 
+// channels [0, n) of a pixel's vector as a 16-channel record of their own, zero padded (n <= 16): the first source of the
+// Winograd form of the NEXT step's FCN conv1 (hcf_engine.hip run_coupling_net)
+template <int CMAX>
+__device__ __forceinline__ void store_pad16(float* out16, size_t pix, int n, const float (&z)[CMAX]) {
+  float* p = out16 + pix * 16;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    step_f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (4 * c4 + e < CMAX && 4 * c4 + e < n) ? z[(4 * c4 + e < CMAX) ? 4 * c4 + e : 0] : 0.f;
+    *reinterpret_cast<step_f32x4*>(p + 4 * c4) = t;
+  }
+}
+
 // Wave-uniform read-only tables (the C x C matrix, ActNorm vectors) are read through the constant address space:
 // scalar loads into SGPRs, which then feed the FMAs directly. Left to itself the compiler reads them with 16+
 // uniform-address vector loads per pixel once the kernel also stores to global memory (it can no longer prove

@@ -116,3 +116,40 @@ def test_engine_uses_winograd_for_the_deep_dense_block_convs():
     assert torch.equal(a, b)
     tol = 2e-5 * max(1.0, float(ex.abs().max()))
     assert maxdiff(a, ex) <= tol and maxdiff(d, ex) <= tol
+
+
+def test_engine_runs_conditional_fcn_conv1_conv2_on_the_winograd_kernel():
+    """Conditional coupling nets (Basic.py:441-447 with cat(z1, features), AffineCouplings.py:65-87): conv1 over [z1 padded to
+    16 | 128 features] runs as ONE 64-channel Winograd launch with the 1x1 conv2 in its epilogue (kind 6); --ablate 512 gives
+    the direct fused kernel (kind 1) back; both stay within the f16x3 tolerance of the exact kernels, and of each other."""
+    from hcflow_amd.config import preset, eps_shapes
+    from tests.util import cached_params, maxdiff
+    from tests.test_gpu_nets import build_net
+    cfg = preset("SR_4X_tiny")
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    g = torch.Generator().manual_seed(6)
+    B, h, w = 2, 37, 50                       # ragged against the 8 x 32 units
+    lr = torch.rand(B, 3, h, w, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, h, w)]
+    with torch.no_grad():
+        ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+        net.set_precision("f16x3")
+        try:
+            eng = net.engine()
+            eng.profile_convs(True)
+            a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            _, n6, _, _ = eng.conv_time(9, 2, kind=6)
+            _, n1, _, _ = eng.conv_time(9, 2, kind=1, reset=True)
+            _ablate(512)
+            d = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            _, m6, _, _ = eng.conv_time(9, 2, kind=6)
+            _, m1, _, _ = eng.conv_time(9, 2, kind=1, reset=True)
+            eng.profile_convs(False)
+            assert eng.fallback_count() == 0
+        finally:
+            _ablate(0)
+            net.set_precision("exact")
+    n_cond = sum(cfg.after)                   # conditional steps per pass
+    assert (n6, n1, m6, m1) == (n_cond, 0, 0, n_cond), (n6, n1, m6, m1, n_cond)
+    tol = 2e-5 * max(1.0, float(ex.abs().max()))
+    assert maxdiff(a, ex) <= tol and maxdiff(d, ex) <= tol and maxdiff(a, d) <= tol

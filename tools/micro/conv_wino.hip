@@ -48,7 +48,19 @@ __global__ void ref_conv(const float* s0, int cs0, int n0, const float* s1, int 
   out[i] = v;
 }
 
-struct Prob { const char* name; int B, H, W, n0, n1, cout, act; bool res; };
+// second layer of the fused form: out[p][oc] = act((sum_ic h[p][ic] w2[oc][ic] + bias2[oc]) * scale2[oc]), fp64
+__global__ void ref_1x1(const float* h, const float* w2, const float* bias2, const float* scale2, int act, long long npix, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * 64) return;
+  const int oc = (int)(i & 63); const long long pix = i >> 6;
+  double s = 0;
+  for (int ic = 0; ic < 64; ++ic) s += (double)h[pix * 64 + ic] * (double)w2[oc * 64 + ic];
+  float v = (float)((s + (double)bias2[oc]) * (double)scale2[oc]);
+  if (act == 1) v = v > 0 ? v : 0; else if (act == 2) v = v > 0 ? v : 0.2f * v;
+  out[i] = v;
+}
+
+struct Prob { const char* name; int B, H, W, n0, n1, cout, act; bool res; bool fuse = false; };
 
 int main(int argc, char** argv) {
   int only = argc > 1 ? atoi(argv[1]) : -1;
@@ -76,6 +88,12 @@ int main(int argc, char** argv) {
       {"fat A L1  64->64  @160", 16, 160, 160, 64, 0, 64, 2, false},
       {"fat B L1  32->32  @160 +partial", 16, 160, 160, 32, 0, 32, 2, true},
       {"fat C L1 128->64  @160", 16, 160, 160, 64, 64, 64, 2, false},
+      // conditional FCN coupling net: conv1 (3x3, [z1 padded to 16 | 128 features] -> 64, ActNorm, ReLU) + conv2 (1x1 64 -> 64) fused
+      {"check fcn 16+128->64 +1x1", 2, 19, 45, 16, 128, 64, 1, false, true},
+      {"check fcn 16+128->64 +1x1 b", 1, 8, 32, 16, 128, 64, 1, false, true},
+      {"fcn cond L0 144->64 +1x1 @320", 16, 320, 320, 16, 128, 64, 1, false, true},
+      {"fcn cond L1 144->64 +1x1 @160", 16, 160, 160, 16, 128, 64, 1, false, true},
+      {"fcn cond L0 144->64 alone @320", 16, 320, 320, 16, 128, 64, 1, false, false},
   };
   const int nprob = sizeof(probs) / sizeof(probs[0]);
   for (int pi = 0; pi < nprob; ++pi) {
@@ -83,7 +101,7 @@ int main(int argc, char** argv) {
     const Prob& P = probs[pi];
     const bool check = P.B * P.H * P.W <= 8192;
     const long long npix = (long long)P.B * P.H * P.W;
-    const int cin = P.n0 + P.n1, cs0 = 64, cs1 = 128;              // x lives in a 64-channel tensor, the growth slab has 128
+    const int cin = P.n0 + P.n1, cs0 = P.n0 < 64 ? P.n0 : 64, cs1 = 128;   // x lives in a 64-channel tensor, the growth slab has 128
     float *s0, *s1, *out, *res, *dw, *dbias, *dscale; char* wpk; int* ovf;
     CK(hipMalloc(&s0, (size_t)npix * cs0 * 4 + 4096)); CK(hipMalloc(&s1, (size_t)npix * cs1 * 4 + 4096));
     CK(hipMalloc(&out, (size_t)npix * 64 * 4)); CK(hipMalloc(&res, (size_t)npix * 64 * 4));
@@ -110,6 +128,19 @@ int main(int argc, char** argv) {
     a.bias = dbias; a.scale = dscale; a.act = P.act; a.out = out; a.out_cs = 64; a.out_c0 = 0; a.cout = P.cout;
     if (P.res) { a.res1 = res; a.res1_cs = 64; a.res1_c0 = 0; a.rs1 = 0.2f; }
     a.ovf = ovf; a.zeros = reinterpret_cast<const char*>(ovf) + 64;
+    std::vector<float> w2(64 * 64), bias2(64), scale2(64);
+    float *dw2 = nullptr, *dbias2 = nullptr, *dscale2 = nullptr; char* dfw = nullptr;
+    if (P.fuse) {
+      for (size_t i = 0; i < w2.size(); ++i) w2[i] = hashf(i, 13) * 0.5f / 8.f;
+      for (int i = 0; i < 64; ++i) { bias2[i] = hashf(i, 15) * 0.1f; scale2[i] = 1.f + 0.1f * hashf(i, 16); }
+      std::vector<uint16_t> fp;
+      if (!pack_weights_1x1_frag(w2.data(), fp)) { printf("1x1 pack failed\n"); return 1; }
+      CK(hipMalloc(&dfw, fp.size() * 2)); CK(hipMemcpy(dfw, fp.data(), fp.size() * 2, hipMemcpyHostToDevice));
+      CK(hipMalloc(&dw2, w2.size() * 4)); CK(hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice));
+      CK(hipMalloc(&dbias2, 256)); CK(hipMalloc(&dscale2, 256));
+      CK(hipMemcpy(dbias2, bias2.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dscale2, scale2.data(), 256, hipMemcpyHostToDevice));
+      a.f_w = dfw; a.f_bias = dbias2; a.f_scale = dscale2; a.f_act = 1;
+    }
     unsigned long long* dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); a.dbg = dbg;
     int rc = (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
@@ -119,6 +150,12 @@ int main(int argc, char** argv) {
       ref_conv<<<(unsigned)((npix * P.cout + 255) / 256), 256>>>(s0, cs0, P.n0, s1, cs1, P.n1, dw, dbias, dscale, P.act, P.res ? res : nullptr, 64,
                                                                 0.2f, P.B, P.H, P.W, P.cout, ref);
       std::vector<float> hr(npix * P.cout), ho(npix * 64);
+      if (P.fuse) {
+        float* ref2; CK(hipMalloc(&ref2, npix * 64 * 4));
+        ref_1x1<<<(unsigned)((npix * 64 + 255) / 256), 256>>>(ref, dw2, dbias2, dscale2, 1, npix, ref2);
+        CK(hipMemcpy(ref, ref2, npix * 64 * 4, hipMemcpyDeviceToDevice));
+        hipFree(ref2);
+      }
       CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
       double md = 0, refmax = 0;
@@ -145,6 +182,7 @@ int main(int argc, char** argv) {
 #endif
     }
     fflush(stdout);
+    hipFree(dfw); hipFree(dw2); hipFree(dbias2); hipFree(dscale2);
     hipFree(s0); hipFree(s1); hipFree(out); hipFree(res); hipFree(ovf); hipFree(wpk); hipFree(dw); hipFree(dbias); hipFree(dscale);
   }
   return 0;
