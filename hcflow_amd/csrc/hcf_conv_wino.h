@@ -572,12 +572,176 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
 // ("rows are in registers") releases the image, and the next chunk's image DMA then has almost a whole chunk to land.
 namespace v4 {
 constexpr int TH4 = 8, HH4 = TH4 + 2;
-constexpr int A4_BYTES = 22 * 1024;               // 1 360 real pieces (10 x 34 pixels x 4 parts) + 48 dead
-constexpr int W4_OFF = A4_BYTES;                  // two weight buffers of W4_BYTES
-constexpr int TAB4_OFF = A4_BYTES + 2 * W4_BYTES; // 153 600
-constexpr int LDS4_BYTES = TAB4_OFF + 1024;       // 154 624 (tables: bias, scale of the conv and of the fused 1x1 layer)
-constexpr int NPIECE4 = 22 + 64;                  // DMA instructions per chunk
+constexpr int A4_BYTES = 22 * 1024;               // 1 360 real pieces (10 x 34 pixels x 4 parts) + 48 dead; TWO image buffers
+constexpr int W4L_BYTES = 48 * 1024;              // a chunk's weights in LDS: [xi 4][nu 4][(tile 0, hi), (tile 0, lo), (tile 1, hi)] x 1 KB;
+                                                  // the lo plane of tile 1 (a quarter of the pack) goes L2 -> registers, see the kernel
+constexpr int W4_OFF0 = 2 * A4_BYTES;             // 45 056
+constexpr int X4_SPARE = 19 * 1024;               // between the weight buffers: either one + the spare >= 64 KB for the epilogue's exchange
+constexpr int W4_OFF1 = W4_OFF0 + W4L_BYTES + X4_SPARE;
+constexpr int TAB4_OFF = W4_OFF1 + W4L_BYTES;     // 162 816
+constexpr int LDS4_BYTES = TAB4_OFF + 1024;       // 163 840 = all of the CU's LDS (tables: bias, scale of the conv and of the fused 1x1 layer)
+constexpr int NPIECE4 = 22 + 48;                  // DMA instructions per chunk
 }  // namespace v4
+
+// Output transform + epilogue of the 64-output-channel kernels (conv_wino4_kernel, conv_wino5_kernel): acc[nu][tile] holds this
+// wave's transform row xi of its tile group tg; `xbase` = 64 KB of LDS nobody else uses until the block's next barrier after the
+// call (the weight buffer just consumed), `tab_off` = the bias / scale tables. Starts with a block barrier.
+template <int RES>
+__device__ __forceinline__ void wino64_epilogue(const Args& a, char* const lds, const int tab_off, char* const xbase, f32x16 (&acc)[4][2],
+                                                const int eb, const int ey0, const int ex0, const int H, const int W, const float slope,
+                                                const float slope2, const float slope_f, const int wave, const int lane) {
+  constexpr bool F1 = (RES == 3);
+  const int half = lane >> 5, li = lane & 31, xi = wave & 3, tg = wave >> 2;
+  (void)li;
+  // ---- epilogue: R[b] = sum_nu M[nu] A[nu][b] per wave (its transform row). The four rows of a tile group meet in LDS
+  // (the weight buffer just consumed), one channel tile per round, and the exchange is also a TRANSPOSE: after it lane
+  // (patch p of 8, register group q, half) of wave xi holds, for patch 8 xi + p, the 4 channels 8 q + 4 half .. + 3 of all four
+  // rows -> y0 = R0 + R1 + R2, y1 = R1 - R2 - R3, and 8 consecutive lanes cover 128 contiguous bytes of one pixel
+  // (residual loads and stores touch 8 cache lines per instruction instead of 32).
+  float chk = 0.f;
+  char* const xbuf = xbase + tg * 32768;
+  const int p8 = lane >> 3, qd = (lane >> 1) & 3, hd = lane & 1;              // reader role
+  const int patch = 8 * xi + p8, prow = patch >> 4, pcol = patch & 15;
+  const int wpos = (half * 32 + ((li + 4 * half) & 31)) * 16;                 // writer slot for even q; odd q: + 8 patches (mod 32)
+  const int wpos1 = (half * 32 + ((li + 4 * half + 8) & 31)) * 16;
+  const int rpos = (hd * 32 + ((patch + 4 * hd + 8 * (qd & 1)) & 31)) * 16 + qd * 1024;
+  f32x4 hv[2][2][2];                              // F1: the first layer's values of this lane (2 rounds x 2 x 2 pixels x 4 channels)
+  __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int cb = nt * 32 + 8 * qd + 4 * hd;
+    f32x4 rv1[2][2], rv2[2][2];                   // this round's residuals: issued now, used after the exchange
+    size_t pixs[2][2];
+    bool oks[2][2];
+#pragma unroll
+    for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) {
+        const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
+        oks[oa][ob] = yy < H && xx < W;
+        pixs[oa][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
+        if (RES == 1 || RES == 2) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[oa][ob] * a.res1_cs + a.res1_c0 + cb);
+        if (RES == 2) rv2[oa][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[oa][ob] * a.res2_cs + a.res2_c0 + cb);
+      }
+    if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's buffer has been read
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 Rq[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        Rq[0][e] = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+        Rq[1][e] = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+      }
+      char* const wbq = xbuf + ((xi * 2) * 4 + q) * 1024 + ((q & 1) ? wpos1 : wpos);
+      *reinterpret_cast<f32x4*>(wbq) = Rq[0];
+      *reinterpret_cast<f32x4*>(wbq + 4096) = Rq[1];
+    }
+    __builtin_amdgcn_s_barrier();
+    f32x4 R[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) R[x][bb] = *reinterpret_cast<const f32x4*>(xbuf + ((x * 2 + bb) * 4) * 1024 + rpos);
+    const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + tab_off + cb * 4);
+    const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + tab_off + 256 + cb * 4);
+    const bool split_t = (nt == 1) && a.out2 != nullptr;         // second tile routed to its own tensor / activation
+    const float slope_t = split_t ? slope2 : slope;
+#pragma unroll
+    for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yv = oa ? (R[1][ob][e] - R[2][ob][e]) - R[3][ob][e] : (R[0][ob][e] + R[1][ob][e]) + R[2][ob][e];
+          chk = fmaf(yv, 0.f, chk);
+          const float z = fmaf(yv, ms[e], bs[e]);
+          v[e] = fmaxf(z, slope_t * z);
+          if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
+          if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
+        }
+        if (F1) hv[nt][oa][ob] = v;
+        else if (oks[oa][ob] && cb < a.cout) {
+          if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pixs[oa][ob] * a.out2_cs + a.out2_c0 + (cb - 32)) = v;
+          else *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
+        }
+      }
+  }
+  if (F1) {
+    // ---- second layer: h2 = act_f((W_f h1 + bias_f) * scale_f) on the tile's 256 pixels. The exchange buffer becomes 256 pixel
+    // records of 256 bytes: 16 slots of 8 halves, slot (plane * 8 + channel / 8) ^ (pixel & 15) (a 128-bit LDS read is served in
+    // groups of 16 lanes, here 16 consecutive pixels -> 16 distinct slots). A wave multiplies 32 pixels (the N of
+    // the matrix instruction) of two tile rows by one 32-channel half of W_f; its A fragments come from L2 (8 KB, lane order).
+    const int mt = wave & 1, r0 = 2 * (wave >> 1);    // this wave: output channels 32 mt .. + 31 of tile rows r0, r0 + 1
+    f16x8 wf[4][2];
+    asm volatile("" ::: "memory");                // (keeps the fragments' registers out of the exchange rounds' live range)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        wf[ks][pl] = *reinterpret_cast<const f16x8*>(a.f_w + (size_t)(((mt * 4 + ks) * 2 + pl) * 64 + lane) * 16);
+    char* const rec = xbase;
+    __builtin_amdgcn_s_barrier();                 // round 1's exchange has been read by every wave
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          const int pi_ = (4 * tg + 2 * prow + oa) * 32 + 2 * pcol + ob;
+          u32x2 h_, l_;
+          split4(hv[nt][oa][ob], h_, l_);
+          char* const rp = rec + pi_ * 256 + hd * 8;
+          *reinterpret_cast<u32x2*>(rp + (((nt * 4 + qd) ^ (pi_ & 15)) << 4)) = h_;
+          *reinterpret_cast<u32x2*>(rp + (((8 + nt * 4 + qd) ^ (pi_ & 15)) << 4)) = l_;
+        }
+    __builtin_amdgcn_s_barrier();
+    f32x16 c2[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c2[rr][r] = 0.f;
+    const char* const rq = rec + (r0 * 32 + li) * 256;
+    const int key = li & 15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const f16x8 vh_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((2 * ks + half) ^ key) << 4));
+        const f16x8 vl_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((8 + 2 * ks + half) ^ key) << 4));
+        c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vh_, c2[rr], 0, 0, 0);
+        c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], vh_, c2[rr], 0, 0, 0);
+        c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vl_, c2[rr], 0, 0, 0);
+      }
+    }
+    const int xx = ex0 + li;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int yy = ey0 + r0 + rr;
+      const bool ok2 = yy < H && xx < W;
+      float* const op = a.out + ((size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (size_t)(xx < W ? xx : W - 1)) * a.out_cs + a.out_c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cb2 = mt * 32 + 8 * q + 4 * half;
+        const f32x4 bs2 = *reinterpret_cast<const f32x4*>(lds + tab_off + 512 + cb2 * 4);
+        const f32x4 ms2 = *reinterpret_cast<const f32x4*>(lds + tab_off + 768 + cb2 * 4);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yv = c2[rr][4 * q + e];
+          chk = fmaf(yv, 0.f, chk);
+          const float z = fmaf(yv, ms2[e], bs2[e]);
+          v[e] = fmaxf(z, slope_f * z);
+        }
+        if (ok2) *reinterpret_cast<f32x4*>(op + cb2) = v;
+      }
+    }
+  }
+  if (__any(chk != chk)) {
+    if (lane == 0) atomicOr(a.ovf, 1);
+  }
+}
 
 template <int RES>
 __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const int nunits) {
@@ -591,8 +755,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   const int H = a.H, W = a.W, nchunk = a.nchunk;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH4 - 1) / TH4;
 
-  // DMA instruction I = 8 j + wave, j = 0..10: I < 22 halo pieces, 22 <= I < 86 weight piece I - 22, I >= 86 nothing.
-  // j = 0, 1: halo; j = 2: halo for waves 0..5, weight pieces 0 / 1 for waves 6 / 7; j = 3..9: weights; j = 10: waves 0..5.
+  // DMA instruction I = 8 j + wave, j = 0..8: I < 22 halo pieces, 22 <= I < 70 weight piece (LDS order) I - 22, I >= 70 nothing.
+  // j = 0, 1: halo; j = 2: halo for waves 0..5, weight pieces 0 / 1 for waves 6 / 7; j = 3..7: weights; j = 8: waves 0..5.
   const bool whi = (wave >= 6);
   const int padpix = a.B * H * W;                // out-of-range pixel index: the DMA writes zeros (conv padding / dead pieces)
   int upix[3];
@@ -637,6 +801,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
     }                                                                                              \
   }
 #define W4_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
+#if !defined(W4_ABL)
+#define W4_ABL 0           // tools/micro timing ablations (results invalid): 1 no weight DMA in the loop, 2 no image DMA, 4 no MFMAs
+#endif
   int csb_ = 0, so_ = 0, ws_ = 0;
   uint32_t pp_ = partpk;
   __amdgpu_buffer_rsrc_t rsa_ = rs0;
@@ -650,29 +817,37 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
     pp_ = partpk;                                                                                  \
     asm volatile("" : "+v"(pp_));                                                                  \
   }
-#define W4_A_SLOT(J)                                                                               \
+#define W4_A_SLOT(J, IB)                                                                           \
   {                                                                                                \
     const int p16_ = (int)((pp_ >> (2 * (J))) & 0x30u);                                            \
     const int vo_ = (int)__umul24((unsigned)upix[J], (unsigned)csb_) + p16_;                       \
-    W4_DMA(rsa_, vo_, so_, lds + (8 * (J) + wave) * 1024);                                         \
+    W4_DMA(rsa_, vo_, so_, lds + (IB) * A4_BYTES + (8 * (J) + wave) * 1024);                       \
   }
-  // halo pieces of the cursor's chunk (the image is single-buffered: only after the "rows are in registers" barrier)
-#define W4_ISSUE_A()                                                                               \
+  // halo pieces of the cursor's chunk into image buffer IB (the one whose rows were read before the last barrier)
+#define W4_ISSUE_A(IB)                                                                             \
   {                                                                                                \
-    W4_A_SLOT(0) W4_A_SLOT(1)                                                                      \
-    if (!whi) W4_A_SLOT(2)                                                                         \
+    W4_A_SLOT(0, IB) W4_A_SLOT(1, IB)                                                              \
+    if (!whi) W4_A_SLOT(2, IB)                                                                     \
   }
-  // weight pieces [J0, J1) (j index) of the cursor's chunk into weight buffer WB
+  // weight pieces [J0, J1) (j index) of the cursor's chunk into weight buffer WB: LDS piece l = xi' * 12 + nu * 3 + s comes
+  // from pack piece xi' * 16 + nu * 4 + s (s = 0, 1, 2: tile 0 hi, tile 0 lo, tile 1 hi)
 #define W4_ISSUE_W(J0, J1, WB)                                                                     \
   {                                                                                                \
-    char* const wb_ = lds + W4_OFF + (WB) * W4_BYTES;                                              \
+    char* const wb_ = lds + ((WB) ? W4_OFF1 : W4_OFF0);                                            \
     _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) {                                       \
-      const int q_ = 8 * j_ + wave - 22;                                                           \
-      if (j_ == 2) { if (whi) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024); }                \
-      else if (j_ < 10) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024);                        \
-      else if (!whi) W4_DMA(rsw, wvo, ws_ + q_ * 1024, wb_ + q_ * 1024);                           \
+      const int l_ = 8 * j_ + wave - 22;                                                           \
+      const int x_ = l_ / 12, r_ = l_ - 12 * x_, n_ = r_ / 3;                                      \
+      const int g_ = x_ * 16 + n_ * 4 + (r_ - 3 * n_);                                             \
+      if (j_ == 2) { if (whi) W4_DMA(rsw, wvo, ws_ + g_ * 1024, wb_ + l_ * 1024); }                \
+      else if (j_ < 8) W4_DMA(rsw, wvo, ws_ + g_ * 1024, wb_ + l_ * 1024);                         \
+      else if (!whi) W4_DMA(rsw, wvo, ws_ + g_ * 1024, wb_ + l_ * 1024);                           \
     }                                                                                              \
   }
+  // the lo plane of channel tile 1 does not go through LDS: this wave's fragment of position NU (pack piece xi * 16 + NU * 4 + 3)
+  // of the cursor's chunk comes straight from L2 into the register the position loop just used for the current chunk's
+  // (inline asm: the compiler's own vmcnt bookkeeping would wait for ALL DMA at the first use; the chunk's top wait covers it)
+  const gcptr w11p = uniform_ptr(a.wpack + (size_t)(xi * 16 + 3) * 1024);
+#define W4_LOAD_W11(NU) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(w11[NU]) : "v"(wvo), "s"(w11p + ws_ + (NU) * 4096) : "memory");
 
   // patch reads: transform row xi uses patch rows (rA, rB) = (0,2) (1,2) (1,2) (1,3): t = rA + sg rB, sg = -1, +1, -1, -1
   const int trow = li >> 4, tcol = li & 15;
@@ -682,7 +857,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #pragma unroll
   for (int j = 0; j < 4; ++j) poff[j] = a2_off(4 * tg + 2 * trow, 2 * tcol + j, 2 * half);
   const int offA = rA * ROWB, offB = rB * ROWB;
-  const int fw = half * 512 + li * 16 + xi * (4 * 4 * 1024);      // + ((nu * 2 + ntile) * 2 + plane) * 1024
+  const int fw = lane * 16 + xi * (12 * 1024);   // + (nu * 3 + s) * 1024
 
   constexpr bool F1 = (RES == 3);                // fused 1x1 second layer (Args::f_w)
   if (tid < 64) {
@@ -699,10 +874,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   unsigned long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long pw_t0 = __builtin_readcyclecounter();
 #endif
+  f16x8 w11[4];
   W4_SETUP_UNIT(u)
   W4_CHUNK_SCALARS()
-  W4_ISSUE_A()
-  W4_ISSUE_W(2, 11, 0)
+  W4_ISSUE_A(0)
+  W4_ISSUE_W(2, 9, 0)
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) W4_LOAD_W11(nu)
   ++uc;
   int g = 0;
   const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
@@ -729,11 +907,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #if defined(WINO_PROF)
       const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-      __builtin_amdgcn_s_barrier();                 // this chunk's image and weights are complete and visible
+      __builtin_amdgcn_s_barrier();                 // this chunk's image, weights and fragments are complete and visible; every
+                                                    // wave is through the previous chunk: its image and weight buffers are free
 #if defined(WINO_PROF)
       const unsigned long long q2 = __builtin_readcyclecounter();
       pw[0] += q1 - q0; pw[1] += q2 - q1;
 #endif
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) asm volatile("" : "+v"(w11[nu]));      // (the fragments were written behind the compiler's back)
       if (c + 1 == nchunk) {
         if (un < nunits) W4_SETUP_UNIT(un)
         else {
@@ -743,15 +924,17 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
         }
       }
       W4_CHUNK_SCALARS()
+      if (!(W4_ABL & 2)) W4_ISSUE_A((g + 1) & 1)    // the next chunk's image: a whole chunk ahead of its first read
       float t_[4][8];
       {
+        const char* const ib = lds + (g & 1) * A4_BYTES;
         float ra[4][8], rb[4][8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 x0_ = *reinterpret_cast<const f32x4*>(lds + poff[j] + offA);
-          const f32x4 x1_ = *reinterpret_cast<const f32x4*>(lds + (poff[j] ^ 16) + offA);
-          const f32x4 y0_ = *reinterpret_cast<const f32x4*>(lds + poff[j] + offB);
-          const f32x4 y1_ = *reinterpret_cast<const f32x4*>(lds + (poff[j] ^ 16) + offB);
+          const f32x4 x0_ = *reinterpret_cast<const f32x4*>(ib + poff[j] + offA);
+          const f32x4 x1_ = *reinterpret_cast<const f32x4*>(ib + (poff[j] ^ 16) + offA);
+          const f32x4 y0_ = *reinterpret_cast<const f32x4*>(ib + poff[j] + offB);
+          const f32x4 y1_ = *reinterpret_cast<const f32x4*>(ib + (poff[j] ^ 16) + offB);
 #pragma unroll
           for (int k = 0; k < 4; ++k) { ra[j][k] = x0_[k]; ra[j][4 + k] = x1_[k]; rb[j][k] = y0_[k]; rb[j][4 + k] = y1_[k]; }
         }
@@ -760,16 +943,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #pragma unroll
           for (int k = 0; k < 8; ++k) t_[j][k] = fmaf(sg, rb[j][k], ra[j][k]);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                 // every wave holds its patch rows in registers: the image may be overwritten
 #if defined(WINO_PROF)
       const unsigned long long q3 = __builtin_readcyclecounter();
       pw[5] += q3 - q2;
 #endif
-      W4_ISSUE_A()
-      const char* const wb = lds + W4_OFF + stg * W4_BYTES + fw;
+      const char* const wb = lds + (stg ? W4_OFF1 : W4_OFF0) + fw;
 #define W4_V(NU, K) (((NU) == 0) ? t_[0][K] - t_[2][K] : ((NU) == 1) ? t_[1][K] + t_[2][K] : ((NU) == 2) ? t_[1][K] - t_[2][K] : t_[1][K] - t_[3][K])
-#define W4_MFMA(P, N, WW, VX) acc[P][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P][N], 0, 0, 0);
+#define W4_MFMA(P, N, WW, VX) if (!(W4_ABL & 4)) acc[P][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P][N], 0, 0, 0); else { acc[P][N][0] += (float)(WW)[0] * (float)__builtin_bit_cast(f16x8, VX)[0]; }
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
         float v_[8];
@@ -777,19 +957,21 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
         for (int k = 0; k < 8; ++k) v_[k] = W4_V(nu, k);
         u32x4 vh_, vl_;
         split8(v_, vh_, vl_);
-        const f16x8 w00 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 0) * 2 + 0) * 1024);
-        const f16x8 w01 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 0) * 2 + 1) * 1024);
-        const f16x8 w10 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 1) * 2 + 0) * 1024);
-        const f16x8 w11 = *reinterpret_cast<const f16x8*>(wb + ((nu * 2 + 1) * 2 + 1) * 1024);
+        const f16x8 w00 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 0) * 1024);
+        const f16x8 w01 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 1) * 1024);
+        const f16x8 w10 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 2) * 1024);
         W4_MFMA(nu, 0, w00, vh_)
         W4_MFMA(nu, 1, w10, vh_)
         W4_MFMA(nu, 0, w01, vh_)
-        W4_MFMA(nu, 1, w11, vh_)
+        W4_MFMA(nu, 1, w11[nu], vh_)
         W4_MFMA(nu, 0, w00, vl_)
         W4_MFMA(nu, 1, w10, vl_)
-        if (nu == 0) { W4_ISSUE_W(2, 5, stg ^ 1) }
-        else if (nu == 1) { W4_ISSUE_W(5, 8, stg ^ 1) }
-        else if (nu == 2) { W4_ISSUE_W(8, 11, stg ^ 1) }
+        if (!(W4_ABL & 1)) {
+          if (nu == 0) { W4_ISSUE_W(2, 5, stg ^ 1) }
+          else if (nu == 1) { W4_ISSUE_W(5, 7, stg ^ 1) }
+          else if (nu == 2) { W4_ISSUE_W(7, 9, stg ^ 1) }
+          W4_LOAD_W11(nu)                         // (this position's fragment of the cursor's chunk, into the register just read)
+        }
       }
       ++uc;
 #if defined(WINO_PROF)
@@ -799,160 +981,12 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #undef W4_MFMA
     }
 
-    // ---- epilogue: R[b] = sum_nu M[nu] A[nu][b] per wave (its transform row). The four rows of a tile group meet in LDS
-    // (the weight buffer just consumed), one channel tile per round, and the exchange is also a TRANSPOSE: after it lane
-    // (patch p of 8, register group q, half) of wave xi holds, for patch 8 xi + p, the 4 channels 8 q + 4 half .. + 3 of all four
-    // rows -> y0 = R0 + R1 + R2, y1 = R1 - R2 - R3, and 8 consecutive lanes cover 128 contiguous bytes of one pixel
-    // (residual loads and stores touch 8 cache lines per instruction instead of 32).
 #if defined(WINO_PROF)
     const unsigned long long qe0 = __builtin_readcyclecounter();
 #endif
-    float chk = 0.f;
-    char* const xbuf = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES + tg * 32768;
-    const int p8 = lane >> 3, qd = (lane >> 1) & 3, hd = lane & 1;              // reader role
-    const int patch = 8 * xi + p8, prow = patch >> 4, pcol = patch & 15;
-    const int wpos = (half * 32 + ((li + 4 * half) & 31)) * 16;                 // writer slot for even q; odd q: + 8 patches (mod 32)
-    const int wpos1 = (half * 32 + ((li + 4 * half + 8) & 31)) * 16;
-    const int rpos = (hd * 32 + ((patch + 4 * hd + 8 * (qd & 1)) & 31)) * 16 + qd * 1024;
-    f32x4 hv[2][2][2];                              // F1: the first layer's values of this lane (2 rounds x 2 x 2 pixels x 4 channels)
-    __builtin_amdgcn_s_barrier();                   // every wave is done reading the last chunk's weights
-#if defined(WINO_PROF)
-    pw[7] += __builtin_readcyclecounter() - qe0;    // (skew of the chunk loop: wait for the slowest wave)
-#endif
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int cb = nt * 32 + 8 * qd + 4 * hd;
-      f32x4 rv1[2][2], rv2[2][2];                   // this round's residuals: issued now, used after the exchange
-      size_t pixs[2][2];
-      bool oks[2][2];
-#pragma unroll
-      for (int oa = 0; oa < 2; ++oa)
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-          const int yy = ey0 + 4 * tg + 2 * prow + oa, xx = ex0 + 2 * pcol + ob;
-          oks[oa][ob] = yy < H && xx < W;
-          pixs[oa][ob] = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1);
-          if (RES == 1 || RES == 2) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[oa][ob] * a.res1_cs + a.res1_c0 + cb);
-          if (RES == 2) rv2[oa][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[oa][ob] * a.res2_cs + a.res2_c0 + cb);
-        }
-      if (nt == 1) __builtin_amdgcn_s_barrier();    // round 0's buffer has been read
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 Rq[2];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * q + e;
-          Rq[0][e] = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
-          Rq[1][e] = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
-        }
-        char* const wbq = xbuf + ((xi * 2) * 4 + q) * 1024 + ((q & 1) ? wpos1 : wpos);
-        *reinterpret_cast<f32x4*>(wbq) = Rq[0];
-        *reinterpret_cast<f32x4*>(wbq + 4096) = Rq[1];
-      }
-      __builtin_amdgcn_s_barrier();
-      f32x4 R[4][2];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) R[x][bb] = *reinterpret_cast<const f32x4*>(xbuf + ((x * 2 + bb) * 4) * 1024 + rpos);
-      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + cb * 4);
-      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 256 + cb * 4);
-      const bool split_t = (nt == 1) && a.out2 != nullptr;         // second tile routed to its own tensor / activation
-      const float slope_t = split_t ? slope2 : slope;
-#pragma unroll
-      for (int oa = 0; oa < 2; ++oa)
-#pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float yv = oa ? (R[1][ob][e] - R[2][ob][e]) - R[3][ob][e] : (R[0][ob][e] + R[1][ob][e]) + R[2][ob][e];
-            chk = fmaf(yv, 0.f, chk);
-            const float z = fmaf(yv, ms[e], bs[e]);
-            v[e] = fmaxf(z, slope_t * z);
-            if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
-            if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
-          }
-          if (F1) hv[nt][oa][ob] = v;
-          else if (oks[oa][ob] && cb < a.cout) {
-            if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pixs[oa][ob] * a.out2_cs + a.out2_c0 + (cb - 32)) = v;
-            else *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
-          }
-        }
-    }
-    if (F1) {
-      // ---- second layer: h2 = act_f((W_f h1 + bias_f) * scale_f) on the tile's 256 pixels. The exchange buffer becomes 256 pixel
-      // records of 256 bytes: 16 slots of 8 halves, slot (plane * 8 + channel / 8) ^ (pixel & 15) (a 128-bit LDS read is served in
-      // groups of 16 lanes, here 16 consecutive pixels -> 16 distinct slots). A wave multiplies 32 pixels (the N of
-      // the matrix instruction) of two tile rows by one 32-channel half of W_f; its A fragments come from L2 (8 KB, lane order).
-      const int mt = wave & 1, r0 = 2 * (wave >> 1);    // this wave: output channels 32 mt .. + 31 of tile rows r0, r0 + 1
-      f16x8 wf[4][2];
-      asm volatile("" ::: "memory");                // (keeps the fragments' registers out of the exchange rounds' live range)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          wf[ks][pl] = *reinterpret_cast<const f16x8*>(a.f_w + (size_t)(((mt * 4 + ks) * 2 + pl) * 64 + lane) * 16);
-      char* const rec = lds + W4_OFF + ((g - 1) & 1) * W4_BYTES;
-      __builtin_amdgcn_s_barrier();                 // round 1's exchange has been read by every wave
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int oa = 0; oa < 2; ++oa)
-#pragma unroll
-          for (int ob = 0; ob < 2; ++ob) {
-            const int pi_ = (4 * tg + 2 * prow + oa) * 32 + 2 * pcol + ob;
-            u32x2 h_, l_;
-            split4(hv[nt][oa][ob], h_, l_);
-            char* const rp = rec + pi_ * 256 + hd * 8;
-            *reinterpret_cast<u32x2*>(rp + (((nt * 4 + qd) ^ (pi_ & 15)) << 4)) = h_;
-            *reinterpret_cast<u32x2*>(rp + (((8 + nt * 4 + qd) ^ (pi_ & 15)) << 4)) = l_;
-          }
-      __builtin_amdgcn_s_barrier();
-      f32x16 c2[2];
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c2[rr][r] = 0.f;
-      const char* const rq = rec + (r0 * 32 + li) * 256;
-      const int key = li & 15;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const f16x8 vh_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((2 * ks + half) ^ key) << 4));
-          const f16x8 vl_ = *reinterpret_cast<const f16x8*>(rq + rr * 8192 + (((8 + 2 * ks + half) ^ key) << 4));
-          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vh_, c2[rr], 0, 0, 0);
-          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][1], vh_, c2[rr], 0, 0, 0);
-          c2[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][0], vl_, c2[rr], 0, 0, 0);
-        }
-      }
-      const int xx = ex0 + li;
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int yy = ey0 + r0 + rr;
-        const bool ok2 = yy < H && xx < W;
-        float* const op = a.out + ((size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (size_t)(xx < W ? xx : W - 1)) * a.out_cs + a.out_c0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cb2 = mt * 32 + 8 * q + 4 * half;
-          const f32x4 bs2 = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 512 + cb2 * 4);
-          const f32x4 ms2 = *reinterpret_cast<const f32x4*>(lds + TAB4_OFF + 768 + cb2 * 4);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float yv = c2[rr][4 * q + e];
-            chk = fmaf(yv, 0.f, chk);
-            const float z = fmaf(yv, ms2[e], bs2[e]);
-            v[e] = fmaxf(z, slope_f * z);
-          }
-          if (ok2) *reinterpret_cast<f32x4*>(op + cb2) = v;
-        }
-      }
-    }
-    if (__any(chk != chk)) {
-      if (lane == 0) atomicOr(a.ovf, 1);
-    }
+    int lane_e = lane;                            // (opaque: the epilogue's lane-constant addresses are recomputed per unit, not kept
+    asm volatile("" : "+v"(lane_e));              //  in registers through the chunk loop, where there are none to spare)
+    wino64_epilogue<RES>(a, lds, TAB4_OFF, lds + (((g - 1) & 1) ? W4_OFF0 + W4L_BYTES : W4_OFF0), acc, eb, ey0, ex0, H, W, slope, slope2, slope_f, wave, lane_e);
 #if defined(WINO_PROF)
     pw[3] += __builtin_readcyclecounter() - qe0;
 #endif
@@ -971,8 +1005,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #undef W4_A_SLOT
 #undef W4_ISSUE_A
 #undef W4_ISSUE_W
+#undef W4_LOAD_W11
 #undef W4_CHUNK_SCALARS
 }
+
 
 static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2) {
   if (a.nsrc < 1 || a.nsrc > 3 || !a.wpack || !a.bias || !a.scale || !a.ovf || !a.zeros || !a.out || a.nchunk < 1) return -1;

@@ -9,6 +9,7 @@
 #include <vector>
 #include "hcf_conv_wino.h"
 #include "hcf_conv_wino_v1.h"      // version 1 of the series (tools/micro only)
+#include "hcf_conv_wino_v5.h"      // version 5: the ping-pong experiment (tools/micro only)
 
 using namespace hcf::wino;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -114,8 +115,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < w.size(); ++i) w[i] = hashf(i, 3) * 0.5f / sqrtf((float)cin * 9.f);
     for (int i = 0; i < P.cout; ++i) { bias[i] = hashf(i, 5) * 0.1f; scale[i] = 1.f + 0.1f * hashf(i, 6); }
     std::vector<uint16_t> pk;
-    const int ver = (version == 4 && P.cout != 64) ? 2 : version;         // v4 is the 64-output-channel kernel
-    if (!(ver == 4 ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
+    const int ver = ((version == 4 || version == 5) && P.cout != 64) ? 2 : version;         // v4 / v5 are the 64-output-channel kernels
+    if (!((ver == 4 || ver == 5) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
@@ -141,8 +142,8 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dbias2, bias2.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dscale2, scale2.data(), 256, hipMemcpyHostToDevice));
       a.f_w = dfw; a.f_bias = dbias2; a.f_scale = dscale2; a.f_act = 1;
     }
-    unsigned long long* dbg; CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); a.dbg = dbg;
-    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
+    unsigned long long* dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128)); a.dbg = dbg;
+    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -167,14 +168,19 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;
       printf("%-34s %9.1f us  %7.1f TF-eq  (%.3f of 833)\n", P.name, us, fl / us / 1e6, fl / us / 1e6 / 833.3);
 #if defined(WINO_PROF)
+      if (ver == 5) { unsigned long long h[16]; CK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost));
+        for (int g = 0; g < 2; ++g) if (h[8 * g + 5]) { const double n = (double)h[8 * g + 5] * 12;   /* 12 launches (warm-up + timed) */
+          printf("    group %d, kcycles per wave and launch: rows %.1f  barrier %.1f  positions %.1f  barrier %.1f  epilogue %.1f\n", g,
+                 h[8 * g] / n / 1e3, h[8 * g + 1] / n / 1e3, h[8 * g + 2] / n / 1e3, h[8 * g + 3] / n / 1e3, h[8 * g + 4] / n / 1e3); } }
+      else
       { unsigned long long h[8]; CK(hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost));
         if (h[4]) printf("    per wave: life %.0f kcyc (%.2f GHz)  vmcnt %.1f %%  barrier %.1f %%  setup+issue %.1f %%  loads+transform %.1f %%  epilogue %.1f %%\n",
                          h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 12 * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]);
