@@ -801,9 +801,6 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
     }                                                                                              \
   }
 #define W4_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
-#if !defined(W4_ABL)
-#define W4_ABL 0           // tools/micro timing ablations (results invalid): 1 no weight DMA in the loop, 2 no image DMA, 4 no MFMAs
-#endif
   int csb_ = 0, so_ = 0, ws_ = 0;
   uint32_t pp_ = partpk;
   __amdgpu_buffer_rsrc_t rsa_ = rs0;
@@ -924,7 +921,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
         }
       }
       W4_CHUNK_SCALARS()
-      if (!(W4_ABL & 2)) W4_ISSUE_A((g + 1) & 1)    // the next chunk's image: a whole chunk ahead of its first read
+      W4_ISSUE_A((g + 1) & 1)                       // the next chunk's image: a whole chunk ahead of its first read
       float t_[4][8];
       {
         const char* const ib = lds + (g & 1) * A4_BYTES;
@@ -949,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #endif
       const char* const wb = lds + (stg ? W4_OFF1 : W4_OFF0) + fw;
 #define W4_V(NU, K) (((NU) == 0) ? t_[0][K] - t_[2][K] : ((NU) == 1) ? t_[1][K] + t_[2][K] : ((NU) == 2) ? t_[1][K] - t_[2][K] : t_[1][K] - t_[3][K])
-#define W4_MFMA(P, N, WW, VX) if (!(W4_ABL & 4)) acc[P][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P][N], 0, 0, 0); else { acc[P][N][0] += (float)(WW)[0] * (float)__builtin_bit_cast(f16x8, VX)[0]; }
+#define W4_MFMA(P, N, WW, VX) acc[P][N] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WW, __builtin_bit_cast(f16x8, VX), acc[P][N], 0, 0, 0);
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
         float v_[8];
@@ -966,12 +963,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
         W4_MFMA(nu, 1, w11[nu], vh_)
         W4_MFMA(nu, 0, w00, vl_)
         W4_MFMA(nu, 1, w10, vl_)
-        if (!(W4_ABL & 1)) {
-          if (nu == 0) { W4_ISSUE_W(2, 5, stg ^ 1) }
-          else if (nu == 1) { W4_ISSUE_W(5, 7, stg ^ 1) }
-          else if (nu == 2) { W4_ISSUE_W(7, 9, stg ^ 1) }
-          W4_LOAD_W11(nu)                         // (this position's fragment of the cursor's chunk, into the register just read)
-        }
+        if (nu == 0) { W4_ISSUE_W(2, 5, stg ^ 1) }
+        else if (nu == 1) { W4_ISSUE_W(5, 7, stg ^ 1) }
+        else if (nu == 2) { W4_ISSUE_W(7, 9, stg ^ 1) }
+        W4_LOAD_W11(nu)                           // (this position's fragment of the cursor's chunk, into the register just read)
       }
       ++uc;
 #if defined(WINO_PROF)

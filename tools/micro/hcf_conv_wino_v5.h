@@ -2,6 +2,9 @@
 // NOT used by the library; tools/micro/conv_wino.hip can time it (version 5). Include after hcf_conv_wino.h.
 #pragma once
 #include "hcf_conv_wino.h"
+#if !defined(W4_ABL)
+#define W4_ABL 0           // timing ablations (results invalid): 1 no weight DMA in the loop, 2 no image DMA, 4 no MFMAs
+#endif
 #if defined(__HIPCC__)
 namespace hcf {
 namespace wino {
