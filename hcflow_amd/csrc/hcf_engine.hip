@@ -853,8 +853,11 @@ struct hcf_engine {
 
   // conditional FCN coupling net as Winograd conv1 + 1x1 conv2 in its epilogue (Step::c1w)?
   bool zpad_valid = false;       // sc.zpad already holds the coming step's z1 (written by the tail of the step before)
+  // the Winograd kernels address their sources with 31-bit byte offsets (an out-of-range offset IS the conv padding): schedules
+  // that cannot fall back per launch (fat dense-block pairs, the FCN form with the 1x1 epilogue) must know beforehand
+  bool wino_offsets_ok(int H, int W, int cs) const { return (long long)B_ * H * W * cs * 4 < 0x7fffe000LL; }
   bool w4f_ok(const Step& s, const View* u, int H, int W, const Scratch& sc) const {
-    return s.fcn && s.w4f_frag && s.cond > 0 && u && s.mode == CPL_AFFINE && can_fuse_fcn(s.c[0], s.c[1]) && !fat_stale && !wino_stale &&
+    return s.fcn && s.w4f_frag && u && wino_offsets_ok(H, W, std::max(u->cs, 16)) && s.w4f_frag && s.cond > 0 && u && s.mode == CPL_AFFINE && can_fuse_fcn(s.c[0], s.c[1]) && !fat_stale && !wino_stale &&
            !(g_f16x3_ablation & (256 | 512)) && u->up == 0 && sc.zpad.p && conv_wino_rounds_ok(B_, H, W, 2);
   }
 
@@ -949,7 +952,8 @@ struct hcf_engine {
     // 61 + 79 at 16 x 160^2) -> up to 200 x 200 pixels per sample. The rule looks at the SAMPLE size, not at the batch: a sample's
     // bits must not depend on how many others share its launch (tests/test_gpu_nets.py: batch independence).
     const bool fat_ok = fatp && fatp->p && use_f16 && !taping && !fat_stale && !wino_stale && !(g_f16x3_ablation & 256) &&
-                        conv_wino_rounds_ok(B_, H, W, 2) && conv_wino_rounds_ok(B_, H, W, 1);
+                        conv_wino_rounds_ok(B_, H, W, 2) && conv_wino_rounds_ok(B_, H, W, 1) &&
+                        wino_offsets_ok(H, W, std::max(std::max(xin.cs, grow.cs), fatp->cs));
     static const long long fat12_pixels = getenv("HCF_FAT12_PIXELS") ? atoll(getenv("HCF_FAT12_PIXELS")) : 40000;   // experiment knob
     const bool use_fat[2] = {fat_ok && r.fat[0] && (long long)H * W <= fat12_pixels, fat_ok && r.fat[1]};
     if (use_fat[0] || use_fat[1]) {

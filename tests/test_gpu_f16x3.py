@@ -177,3 +177,25 @@ def test_large_grid_forward_nll_f16x3_is_deterministic():
 
 def _as_list(z):
     return list(z) if isinstance(z, (list, tuple)) else [z]
+
+
+def test_huge_image_takes_the_per_launch_fallbacks():
+    """One 1024 x 1040 LR image (level 0: 2048 x 2080 pixels x 128-channel tensors = more than the 2 GB that the Winograd kernels'
+    31-bit source offsets can address): the schedules that cannot fall back per launch (fat dense-block pairs, the FCN form with
+    the 1x1 epilogue) must step aside beforehand, the plain Winograd launches fall back to the direct kernels one by one, and the
+    pass still agrees with the exact kernels."""
+    cfg = preset("SR_4X_tiny")
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    g = torch.Generator().manual_seed(23)
+    h, w = 1024, 1040
+    lr = torch.rand(1, 3, h, w, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, 1, h, w)]
+    with torch.no_grad():
+        ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+        net.set_precision("f16x3")
+        try:
+            a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            assert net.engine().fallback_count() == 0
+        finally:
+            net.set_precision("exact")
+    assert maxdiff(a, ex) <= 2e-5 * max(1.0, float(ex.abs().max()))

@@ -21,6 +21,8 @@ SHAPES = [
     ("fcn_conv1_L0c 3+128->64  @320", 16, 320, 320, [3, 128], 64, 3),
     ("fcn_conv3_L0c 64->6      @320", 16, 320, 320, [64], 6, 3),
     ("fcn_conv2     64->64 1x1 @320", 16, 320, 320, [64], 64, 1),
+    ("completion    32->32     @320", 16, 320, 320, [32], 32, 3),      # the direct kernel on the fat schedule's completion shape
+    ("completion    32->32     @160", 16, 160, 160, [32], 32, 3),
 ]
 
 
