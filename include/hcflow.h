@@ -115,8 +115,10 @@ int hcf_inverse(hcf_engine* e, const float* lr, const float* const* eps, int32_t
                 float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
 /* The same for a SHARD of a larger batch (batch-sharded multi-GPU sampling): sample b of this call is sample
  * first_sample + b of the batch, and the device Philox draws are those of that global sample -- N shards with the same seed
- * reproduce the one-GPU batch bit for bit (the reference seeds every rank identically, train_HCFlow.py:43-46, which would give
- * every shard the same eps). hcf_inverse = first_sample 0. */
+ * draw exactly the eps of the one-GPU batch (the reference seeds every rank identically, train_HCFlow.py:43-46, which would give
+ * every shard the same eps). The IMAGES are bit-identical when the shards take the same kernel schedule as the full batch
+ * (always for equal per-sample sizes at the BASELINE shapes; a layer's Winograd / direct choice follows how many units a launch
+ * has, so very small or very large shards agree to fp32 rounding instead). hcf_inverse = first_sample 0. */
 int hcf_inverse_ex(hcf_engine* e, const float* lr, const float* const* eps, int32_t n_eps, float tau, uint64_t seed,
                    int64_t first_sample, float* out_hr, int32_t B, int32_t h, int32_t w, uint32_t flags, hcf_stream_t stream);
 
