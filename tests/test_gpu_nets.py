@@ -359,3 +359,13 @@ def test_rebinding_to_new_parameter_tensors_refreshes_on_device():
     with torch.no_grad():                                   # leave the cached module as other tests expect it
         for k, p in net.named_parameters():
             p.data = pa[k].to("cuda:0").clone()
+
+
+def test_empty_batch_samples_to_an_empty_batch():
+    """netG(lr=<0 images>, reverse=True): the reference's reverse path (HCFlowNet_SR_arch.py:70-75) is convs / elementwise ops /
+    randn over the batch axis, all of which accept B = 0; the engine entry rejects B < 1, so the module answers itself."""
+    cfg = preset("SR_4X_tiny")
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    with torch.no_grad():
+        out = net(lr=torch.zeros(0, 3, 12, 20).cuda(), eps_std=0.8, reverse=True)
+    assert tuple(out.shape) == (0, 3, 48, 80) and out.dtype == torch.float32 and out.is_cuda
