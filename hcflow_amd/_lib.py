@@ -271,7 +271,7 @@ class Engine:
     def conv_time(self, taps: int = 0, nt: int = 0, reset: bool = False, kind: int = -1):
         """(total_ms, launches, algorithmic_flops, algorithmic_bytes) of the recorded conv launches of one variant
         (kind: 0 plain, 1 fused 1x1 second layer, 2 fused flow-step tail, 3 upsampled source, 4 Winograd form, 5 persistent small-K FCN kernel,
-        6 Winograd conv1 + 1x1 conv2 of a conditional FCN, -1 any)."""
+        6 Winograd conv1 + 1x1 conv2 of a conditional FCN, 7 completion of a fat dense-block launch, -1 any)."""
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         check(self.lib.hcf_conv_time_ms(self._h, taps, nt, kind, int(reset), C.byref(ms), C.byref(n), C.byref(fl),
                                         C.byref(by)), self._h, "hcf_conv_time_ms")

@@ -685,7 +685,7 @@ struct hcf_engine {
       a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
       if (w4f) { a.wf1x1 = fat->w4f_frag; a.bias2 = fuse2->bias; a.scale2 = fuse2->scale; a.act2 = fuse2->act; }
       r = launch_conv_wino(a, cv.wpack_wino, st);      // HCF_ERR_UNSUPPORTED: this call's views do not qualify
-      if (r == HCF_OK && prof) prof_events[prof_used].kind = w4f ? 6 : 4;
+      if (r == HCF_OK && prof) prof_events[prof_used].kind = w4f ? 6 : (fat && fat->pre) ? 7 : 4;
     }
     if (fat && r != HCF_OK) { fail(HCF_ERR_STATE, "internal: a fat dense-block launch did not take the Winograd kernel"); return; }
     if (r != HCF_ERR_UNSUPPORTED) {

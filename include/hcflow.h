@@ -215,7 +215,7 @@ int hcf_get_param(hcf_engine* e, const char* key, float* host_out, int64_t numel
  * (taps in {9,1} = 3x3 / 1x1, nt = N tiles of 32 output channels; 0 = any; kind = 0 plain conv, 1 with the fused
  * 1x1 second layer, 2 with the fused flow-step tail, 3 reading an upsampled source, 4 the Winograd form of the f16x3
  * conv, 5 the persistent small-K FCN conv1 + conv2 kernel (hcf_conv_fcn.hip), 6 the Winograd form of a conditional FCN
- * conv1 with the 1x1 conv2 in its epilogue, -1 any): total time, launch count,
+ * conv1 with the 1x1 conv2 in its epilogue, 7 the 32 -> 32 completion of a fat dense-block launch (adds a stored partial), -1 any): total time, launch count,
  * algorithmic FLOPs (2 * taps * cin * cout per output pixel) and algorithmic HBM bytes (each source window,
  * residual and the weights read once, the output written once). reset != 0 clears the records. */
 int hcf_profile_convs(hcf_engine* e, int enable);
