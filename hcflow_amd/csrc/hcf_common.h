@@ -69,6 +69,9 @@ struct ConvArgs {
   // 64-channel Winograd kernel only: the 1x1 second layer of an FCN coupling net in its epilogue (hcf_conv_wino.h Args::f_w);
   // wf1x1 = wino::pack_weights_1x1_frag of the 64 x 64 weights, bias2 / scale2 / act2 as for the fused f16x3 form
   const void* wf1x1;
+  // Winograd kernels only: the pack's channel tiles (1 / 2) when the real output width is not 32 / 64 (a DenseBlock coupling net's
+  // last conv: 3 .. 42 channels, computed as a zero-padded tile and stored up to the next multiple of 4); 0: out.n / 32
+  int wino_ntile;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -281,6 +284,7 @@ int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t s
 int launch_haar_inv(View in, View out, int B, int C4, int H, int W, hipStream_t st);
 int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st);
 int launch_copy_pad16(View in, float* out16, int B, int H, int W, hipStream_t st);   // [B, H, W, 16]: channels of `in` (<= 16), then zeros
+int launch_copy_pad(View in, View out, int B, int H, int W, hipStream_t st);         // out.n (a multiple of 16) channels: `in`'s, then zeros
 // SR forward tail: zq = round(clamp(z,0,1)*255)/255 ; lr_hat NCHW = zq ; partial += logp(lr; mean zq, logs -6)
 int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W,
                       float* partial, int partial_stride, hipStream_t st);

@@ -1020,7 +1020,7 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (a.res2 && (((a.res2_cs | a.res2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.res2) & 15))) return -6;
   if (a.res2 && !a.res1) return -1;
   if ((long long)a.B * a.H * a.W >= (1LL << 24)) return -6;                            // 24-bit pixel index (mul24)
-  if (version == 4 && (a.ntile_n != 2 || a.cout != 64)) return -6;
+  if (version == 4 && (a.ntile_n != 2 || a.cout > 64)) return -6;
   const int th = (version == 2) ? v2::TH2 : (version == 4) ? v4::TH4 : TH;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + th - 1) / th;
   const long long nunits = (long long)a.B * tiles_x * tiles_y * (version == 4 ? 1 : a.ntile_n);

@@ -107,10 +107,11 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   w.B = a.B; w.H = a.H; w.W = a.W;
   w.wpack = reinterpret_cast<const char*>(wpack_wino);
   w.nchunk = cin / 16;
-  w.ntile_n = a.out.n / 32;
-  if (w.ntile_n * 32 != a.out.n) return HCF_ERR_UNSUPPORTED;
+  w.ntile_n = a.wino_ntile > 0 ? a.wino_ntile : a.out.n / 32;
+  w.cout = a.wino_ntile > 0 ? ((a.out.n + 3) & ~3) : a.out.n;      // (the padded tile's extra channels are zeros: stored up to the next 4)
+  if (a.wino_ntile > 0 ? (w.cout > 32 * w.ntile_n || w.cout > a.out.cs - a.out.c0) : (w.ntile_n * 32 != a.out.n)) return HCF_ERR_UNSUPPORTED;
   w.bias = a.bias; w.scale = a.scale; w.act = a.act;
-  w.out = a.out.p; w.out_cs = a.out.cs; w.out_c0 = a.out.c0; w.cout = a.out.n;
+  w.out = a.out.p; w.out_cs = a.out.cs; w.out_c0 = a.out.c0;
   if (a.res1.p && a.res1_pre) { w.pre = a.res1.p; w.pre_cs = a.res1.cs; w.pre_c0 = a.res1.c0; }
   else if (a.res1.p) { w.res1 = a.res1.p; w.res1_cs = a.res1.cs; w.res1_c0 = a.res1.c0; w.rs1 = a.rs1; }
   if (a.wf1x1) {

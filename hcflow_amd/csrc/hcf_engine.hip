@@ -39,13 +39,14 @@ struct Spec {
 };
 
 // One fused conv layer, packed for conv_mfma_kernel
-extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip (hcf_debug_set_ablation; bit 256: no Winograd kernels, bit 512: no Winograd form of FCN conv1 + conv2)
+extern int g_f16x3_ablation;   // hcf_conv_f16x3.hip (hcf_debug_set_ablation; bit 256: no Winograd kernels, bit 512: no Winograd form of FCN conv1 + conv2, bit 1024: no Winograd form of the DenseBlock coupling convs)
 
 struct Conv {
   int taps = 9, cout = 0, nsrc = 0, src_n[kMaxSrc] = {0, 0, 0}, nchunk = 0, npad = 0, act = ACT_NONE;
   float *wpack = nullptr, *bias = nullptr, *scale = nullptr;   // device
   float* wpack16 = nullptr;                                     // device, f16x3 split pack (or null: exact only)
   float* wpack_wino = nullptr;                                  // device, Winograd f16x3 pack (eligible dense-block convs only)
+  int wino_ntile = 0;                                           // > 0: the pack's channel tiles when cout is not 32 / 64 (zero-padded rows)
   double flops_per_pixel = 0;                                   // 2 * taps * cin * cout (algorithmic)
   std::string an_key;                                           // Basic.Conv2d: prefix of its ActNorm ("....conv1.actnorm")
   // training path: state_dict keys of the parameters behind this layer and what the epilogue sums mean for them
@@ -69,6 +70,11 @@ struct Step {
   // conv2 (1x1) in its epilogue (profiles/r03_notes.md section 8). c1w = c[0] with that source list and pack; built by finalize.
   Conv c1w;
   float* w4f_frag = nullptr;
+  // DenseBlock coupling nets (the rescaling nets' steps, Basic.py:329-356), f16x3 inference: conv i >= 1 in Winograd form over
+  // [z1 padded to whole 16-channel chunks | growth]; cw[i] = c[i] with that source list, pack and (last conv) a zero-padded
+  // output tile. dw_pad = the padded width of z1 (0: none of this).
+  Conv cw[5];
+  int dw_pad = 0;
   float *mat_fwdT = nullptr;        // training: W^T padded [cmax][cmax] (gza = W^T gzb)
   float *winvT = nullptr;           // training: W^-T, [C][C] unpadded (d slogdet / dW)
   float *mat_invT = nullptr;        // training: (W^-1)^T padded [cmax][cmax] (reverse path: gzc = W^-T gy)
@@ -449,6 +455,31 @@ struct hcf_engine {
         build_conv(s.c[i], f + ".conv" + std::to_string(i + 1), s.f_in + i * hid, i < 4 ? hid : s.f_out, srcs,
                    i < 4 ? ACT_LRELU : ACT_NONE);
       }
+      s.dw_pad = 0;
+      for (int i = 0; i < 5; ++i) s.cw[i] = Conv();
+      static const bool no_dw = getenv("HCF_NO_DENSE_WINO") != nullptr;      // A/B knob, read once
+      if (!spec_mode && rc == HCF_OK && wino_enabled && !no_dw && cond == 0 && hid >= 16 && (hid & 15) == 0 && z1_n <= 48 && s.f_out <= 64) {
+        const int npad = (z1_n + 15) & ~15;
+        bool any = false;
+        for (int i = 1; i < 5; ++i) {
+          const int cin = s.f_in + i * hid, cin_p = npad + i * hid, cout = i < 4 ? hid : s.f_out, cout_t = cout <= 32 ? 32 : 64;
+          const std::vector<float>& w = params[f + ".conv" + std::to_string(i + 1) + ".weight"].data;
+          if (cin_p < 48 || !s.c[i].wpack16 || w.size() != (size_t)cout * cin * 9) continue;
+          std::vector<float> wp((size_t)cout_t * cin_p * 9, 0.f), pk;
+          for (int oc = 0; oc < cout; ++oc)
+            for (int ic = 0; ic < cin; ++ic)
+              memcpy(&wp[((size_t)oc * cin_p + (ic < z1_n ? ic : ic - z1_n + npad)) * 9], &w[((size_t)oc * cin + ic) * 9], 9 * sizeof(float));
+          const int sp[2] = {npad, i * hid};
+          if (!pack_conv_weights_wino(wp.data(), cin_p, cout_t, sp, 2, pk, 48)) continue;
+          s.cw[i] = s.c[i];
+          s.cw[i].src_n[0] = npad;
+          s.cw[i].wpack_wino = upload(pk);
+          s.cw[i].wino_ntile = (cout == 32 || cout == 64) ? 0 : cout_t / 32;
+          s.cw[i].tpacks.clear();
+          any = true;
+        }
+        if (any) s.dw_pad = npad;
+      }
     }
     if (spec_mode || rc != HCF_OK) return;
     const int M = s.cmax;
@@ -652,6 +683,7 @@ struct hcf_engine {
     a.out = out; a.out.n = cv.cout;
     a.res1 = res1; a.rs1 = rs1; a.res2 = res2; a.rs2 = rs2;
     if (fat) { a.out2 = fat->out2; a.act_t2 = fat->act2; a.res1_pre = fat->pre ? 1 : 0; }
+    a.wino_ntile = cv.wino_ntile;
     if (dry()) return;
     if (prof) {
       if (prof_used == prof_events.size()) {
@@ -838,7 +870,7 @@ struct hcf_engine {
   }
 
   struct Scratch {      // per-level temporaries
-    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow, fatp, zpad;
+    Buf h1, h2, hout, grow, t1, t2, x, f0, rgrow, fatp, zpad, zpadd;
   };
 
   // coupling network f(z1 [, u]) -> sc.hout   (FCN: Basic.py:441-447, DenseBlock: :349-356)
@@ -888,11 +920,24 @@ struct hcf_engine {
         run_conv(s.c[2], {sc.h2.v(0, s.hid)}, H, W, sc.hout.v(0, s.f_out), none, 0.f, none, 0.f, nullptr, tail);
       }
     } else {
+      // DenseBlock: conv i >= 1 in Winograd form over [z1 padded | growth] where that form exists and this level qualifies
+      bool need64 = false;
+      for (int i = 1; i < 5; ++i) need64 = need64 || (s.cw[i].wpack_wino && (s.cw[i].wino_ntile == 2 || s.cw[i].cout == 64));
+      const bool dw = s.dw_pad > 0 && s.cond == 0 && use_f16 && !taping && !fat_stale && !wino_stale && !(g_f16x3_ablation & (256 | 1024)) &&
+                      sc.zpadd.p && sc.zpadd.C >= s.dw_pad && conv_wino_rounds_ok(B_, H, W, 1) && (!need64 || conv_wino_rounds_ok(B_, H, W, 2)) &&
+                      wino_offsets_ok(H, W, std::max(sc.grow.cs, sc.zpadd.cs));
+      if (dw) HCF_LAUNCH(launch_copy_pad(z1, sc.zpadd.v(0, s.dw_pad), B_, H, W, st));
       for (int i = 0; i < 5; ++i) {
+        const View out_i = i < 4 ? sc.grow.v(i * s.hid, s.hid) : sc.hout.v(0, s.f_out);
+        if (dw && s.cw[i].wpack_wino) {
+          const View none = mkview(nullptr, 0, 0, 0);
+          const FatExtra fx = {none, ACT_NONE, false, nullptr};       // (no per-launch fallback: the direct packs have another source list)
+          run_conv(s.cw[i], {sc.zpadd.v(0, s.dw_pad), sc.grow.v(0, i * s.hid)}, H, W, out_i, none, 0.f, none, 0.f, nullptr, nullptr, &fx);
+          continue;
+        }
         std::vector<View> srcs = in;
         if (i > 0) srcs.push_back(sc.grow.v(0, i * s.hid));
-        if (i < 4) run_conv(s.c[i], srcs, H, W, sc.grow.v(i * s.hid, s.hid));
-        else run_conv(s.c[i], srcs, H, W, sc.hout.v(0, s.f_out));
+        run_conv(s.c[i], srcs, H, W, out_i);
       }
     }
   }
@@ -1068,6 +1113,12 @@ struct hcf_engine {
     sc.rgrow = alloc(B_, H, W, 4 * cfg.rrdb_gc);
     sc.fatp = alloc(B_, H, W, cfg.rrdb_gc);          // stored partial sum of the fat dense-block launches
     sc.zpad = alloc(B_, H, W, 16);                   // z1 of a conditional coupling net, zero padded (Step::c1w)
+    int dwp = 0;
+    for (const Level& lv : levels) {
+      for (const Step& s : lv.steps) dwp = std::max(dwp, s.dw_pad);
+      for (const Step& s : lv.cf.steps) dwp = std::max(dwp, s.dw_pad);
+    }
+    sc.zpadd = alloc(B_, H, W, std::max(4, dwp));    // ... of a DenseBlock coupling net (Step::cw)
     return sc;
   }
 

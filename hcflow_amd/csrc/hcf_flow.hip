@@ -363,19 +363,20 @@ __global__ __launch_bounds__(256) void copy_view_kernel(View in, View out, int h
   for (int c = 0; c < in.n; ++c) op[c] = ip[c];
 }
 
-// z1 of a conditional coupling net as a 16-channel tensor of its own (zero padded): the first source of the Winograd form of
-// FCN conv1, whose sources are whole 16-channel chunks (hcf_engine.hip run_coupling_net)
-__global__ __launch_bounds__(256) void copy_pad16_kernel(View in, float* __restrict__ out16, int hw) {
+// z1 of a coupling net as a tensor of its own, zero padded to whole 16-channel chunks (out.n = 16 / 32 / 48 at stride out.cs): the
+// first source of the Winograd form of the net's first convs, whose sources are whole chunks (hcf_engine.hip run_coupling_net)
+__global__ __launch_bounds__(256) void copy_pad_kernel(View in, View out, int hw) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= hw) return;
   const size_t pix = (size_t)blockIdx.y * hw + i;
   const float* ip = in.p + pix * in.cs + in.c0;
-  float v[16];
+  float4* op = reinterpret_cast<float4*>(out.p + pix * out.cs + out.c0);
+  for (int k = 0; k < out.n / 4; ++k) {
+    float v[4];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) v[c] = c < in.n ? ip[c] : 0.f;
-  float4* op = reinterpret_cast<float4*>(out16 + pix * 16);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) op[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    for (int e = 0; e < 4; ++e) v[e] = (4 * k + e < in.n) ? ip[4 * k + e] : 0.f;
+    op[k] = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 // Quant (Basic.py:187-191) + logp(lr, logs=-6, zq) (HCFlowNet_SR_arch.py:58-63); z has 3 channels
@@ -528,10 +529,13 @@ int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st) {
   hipLaunchKernelGGL(copy_view_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, H * W);
   HCF_RET();
 }
-int launch_copy_pad16(View in, float* out16, int B, int H, int W, hipStream_t st) {
-  if (in.n < 1 || in.n > 16 || !out16) return HCF_ERR_ARG;
-  hipLaunchKernelGGL(copy_pad16_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out16, H * W);
+int launch_copy_pad(View in, View out, int B, int H, int W, hipStream_t st) {
+  if (in.n < 1 || in.n > out.n || (out.n & 15) || ((out.cs | out.c0) & 3) || !out.p) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(copy_pad_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, H * W);
   HCF_RET();
+}
+int launch_copy_pad16(View in, float* out16, int B, int H, int W, hipStream_t st) {
+  return launch_copy_pad(in, mkview(out16, 16, 0, 16, 0), B, H, W, st);
 }
 int launch_quant_logp(View z, const float* lr_nchw, float* lr_hat_nchw, int B, int H, int W, float* partial,
                       int partial_stride, hipStream_t st) {

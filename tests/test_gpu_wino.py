@@ -153,3 +153,44 @@ def test_engine_runs_conditional_fcn_conv1_conv2_on_the_winograd_kernel():
     assert (n6, n1, m6, m1) == (n_cond, 0, 0, n_cond), (n6, n1, m6, m1, n_cond)
     tol = 2e-5 * max(1.0, float(ex.abs().max()))
     assert maxdiff(a, ex) <= tol and maxdiff(d, ex) <= tol and maxdiff(a, d) <= tol
+
+
+def test_engine_runs_denseblock_coupling_convs_on_the_winograd_kernels():
+    """Rescaling nets: the DenseBlock coupling nets (Basic.py:329-356) read cat(z1, growth): with z1 (3 / 9 / 21 channels) padded to
+    whole 16-channel chunks conv2 .. conv5 take the Winograd form (the last one as a zero-padded output tile: 3 / 18 / 42 real
+    channels); --ablate 1024 gives the direct kernels back; forward (encode) and inverse (decode) both, within the f16x3 tolerance
+    of the exact kernels and of each other."""
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, maxdiff
+    from tests.test_gpu_nets import build_net
+    cfg = preset("Rescaling_4X_tiny")
+    net = build_net(cfg, cached_params("Rescaling_4X_tiny", 13))
+    g = torch.Generator().manual_seed(8)
+    hr = torch.rand(2, 3, 136, 200, generator=g).cuda()                 # ragged against the 16 x 32 units at both levels
+    n_dense = sum(cfg.K[:cfg.L]) - sum(cfg.after)                       # DenseBlock steps per pass
+    with torch.no_grad():
+        lr_e = net(hr=hr, reverse=False)[0]
+        rec_e = net(lr=lr_e, reverse=True, eps_std=0.0)
+        net.set_precision("f16x3")
+        try:
+            eng = net.engine()
+            eng.profile_convs(True)
+            lr_a = net(hr=hr, reverse=False)[0]
+            n_fwd = eng.conv_time(9, 0, kind=4, reset=True)[1]
+            rec_a = net(lr=lr_e, reverse=True, eps_std=0.0)
+            n_inv = eng.conv_time(9, 0, kind=4, reset=True)[1]
+            _ablate(1024)
+            lr_d = net(hr=hr, reverse=False)[0]
+            m_fwd = eng.conv_time(9, 0, kind=4, reset=True)[1]
+            rec_d = net(lr=lr_e, reverse=True, eps_std=0.0)
+            eng.profile_convs(False)
+            assert eng.fallback_count() == 0
+        finally:
+            _ablate(0)
+            net.set_precision("exact")
+    assert n_fwd - m_fwd == 4 * n_dense and n_inv >= 4 * n_dense, (n_fwd, m_fwd, n_inv, n_dense)
+    tol = 2e-5 * max(1.0, float(rec_e.abs().max()))
+    assert maxdiff(rec_a, rec_e) <= tol and maxdiff(rec_d, rec_e) <= tol and maxdiff(rec_a, rec_d) <= tol
+    # the quantised LR image: a level may flip where the pre-quantisation value sits on a rounding boundary
+    for x in (lr_a, lr_d):
+        assert float(((x - lr_e).abs() > 0.5 / 255).float().mean()) <= 1e-3
