@@ -51,10 +51,13 @@ def batched_test_loader(dataset, batch_size: int = 16, keys: Sequence[str] = ("L
 
 
 def evaluate_batch(net, batch: Dict, heats: Iterable[float], n_sample: int, scale: int, crop_border: Optional[int] = None,
-                   seed: Optional[int] = None, noise: Optional[torch.Tensor] = None) -> List[Dict]:
+                   seed: Optional[int] = None, noise: Optional[torch.Tensor] = None, lpips_fn=None) -> List[Dict]:
     """Per image of the batch: {"nll": float, "lr": {psnr, ssim, psnr_y, ssim_y} of LR^ vs LQ (SR nets), and per heat:
     {"psnr", "ssim", "psnr_y", "ssim_y", "bic_psnr", ... (means over the samples), "diversity"}} -- the numbers of the
-    reference's per-image log line (test_HCFlow.py:166-175) without LPIPS. ``net`` is an eval()-mode HCFlowNet_SR on a GPU.
+    reference's per-image log line (test_HCFlow.py:166-175). LPIPS needs the ``lpips`` package's pretrained AlexNet: pass the
+    caller's own module as ``lpips_fn`` (``lpips.LPIPS(net='alex').to('cuda')``, test_HCFlow.py:48) and every heat entry gets
+    "lpips" = the mean over the samples of ``lpips_fn(2 gt - 1, 2 sr - 1)`` per image (:132-133, :168), evaluated on the whole
+    batch at once; without it the key is absent. ``net`` is an eval()-mode HCFlowNet_SR on a GPU.
     ``seed`` fixes the device draws of the samples, ``noise`` ([B,3,H,W] in [0,1)) replaces the dequantisation noise of the
     NLL pass (HCFlowNet_SR_arch.py:52); both default to fresh draws, as in the reference."""
     dev = next(net.parameters()).device
@@ -76,6 +79,7 @@ def evaluate_batch(net, batch: Dict, heats: Iterable[float], n_sample: int, scal
         for hi, heat in enumerate(heats):
             samples = []
             acc = [dict.fromkeys(M.KEYS, 0.0) for _ in range(B)]
+            lp = [0.0] * B
             for s in range(n_sample):
                 kw = {} if seed is None else {"seed": seed + 1000 * hi + s}
                 sr = net(lr=lq, z=None, u=None, eps_std=heat, reverse=True, training=False, **kw)
@@ -84,8 +88,14 @@ def evaluate_batch(net, batch: Dict, heats: Iterable[float], n_sample: int, scal
                     for b, m in enumerate(M.psnr_ssim(gt, sr, crop, scale)):
                         for k in M.KEYS:
                             acc[b][k] += m[k] / n_sample
+                    if lpips_fn is not None:
+                        d = lpips_fn(2 * gt - 1, 2 * sr - 1).reshape(B, -1).mean(dim=1)      # [B, 1, 1, 1] -> one value per image
+                        for b, v in enumerate(d.double().cpu().tolist()):
+                            lp[b] += v / n_sample
             for b in range(B):
                 ent = dict(acc[b]) if gt is not None else {}
+                if gt is not None and lpips_fn is not None:
+                    ent["lpips"] = lp[b]
                 ent["diversity"] = M.diversity([s[b:b + 1] for s in samples]) if n_sample > 1 else 0.0
                 res[b][float(heat)] = ent
     return res

@@ -94,3 +94,35 @@ def test_batched_evaluation_equals_one_image_at_a_time():
         for k in ("psnr", "ssim", "bic_psnr", "bic_ssim_y"):
             assert abs(t_[0.0][k] - a_[0.0][k]) <= 1e-9 * max(1.0, abs(a_[0.0][k])), k
         assert set(t_[0.8].keys()) >= {"psnr", "ssim", "diversity"}
+
+
+def test_lpips_hook_receives_the_reference_inputs_per_image():
+    """evaluate_batch(lpips_fn=...): the caller's own lpips module (the package's pretrained AlexNet cannot be rebuilt offline)
+    gets (2 gt - 1, 2 sr - 1) as in test_HCFlow.py:132 and returns [B, 1, 1, 1]; the entry is the per-image mean over samples.
+    Checked with a stand-in distance whose per-image value is known."""
+    from hcflow_amd import HCFlowNet_SR, preset, make_params
+    from hcflow_amd.loader import batched_test_loader, evaluate_batch
+    from tests.test_loader_cpu import FakeSet
+    cfg = preset("SR_4X_tiny")
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(make_params(cfg, 11), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.cuda().eval()
+    seen = []
+
+    def fake_lpips(a, b):              # a "distance" in the [-1, 1] domain: mean |a - b| per image, shaped like lpips' output
+        seen.append((float(a.min()), float(a.max()), tuple(a.shape), tuple(b.shape)))
+        return (a - b).abs().mean(dim=(1, 2, 3), keepdim=True)
+
+    ds = FakeSet([(12, 16)] * 3)
+    b = next(iter(batched_test_loader(ds, 3)))
+    res = evaluate_batch(net, b, [0.0], n_sample=2, scale=4, seed=3, lpips_fn=fake_lpips)
+    assert len(seen) == 2 and all(s[2] == s[3] == (3, 3, 48, 64) and -1.0 <= s[0] and s[1] <= 1.0 for s in seen)
+    with torch.no_grad():
+        sr = net(lr=b["LQ"].cuda(), eps_std=0.0, reverse=True)
+    want = (2 * (b["GT"].cuda() - sr)).abs().mean(dim=(1, 2, 3)).cpu().tolist()           # tau = 0: both samples are identical
+    for r, w in zip(res, want):
+        assert abs(r[0.0]["lpips"] - w) <= 1e-6
+    assert "lpips" not in evaluate_batch(net, b, [0.0], n_sample=1, scale=4)[0][0.0]
