@@ -211,3 +211,81 @@ def test_random_rescaling_configurations_match_oracle(seed):
     assert float((z1g.cpu() - z1o).abs().max()) <= 1e-4 * max(1.0, float(z1o.abs().max()))
     assert float((z2g.cpu() - z2o).abs().max()) <= 1e-4 * max(1.0, float(z2o.abs().max()))
     assert float((inv_g.cpu() - inv_o).abs().max()) <= 1e-4 * max(1.0, float(inv_o.abs().max()))
+
+
+# ---- the same random configurations on the DEFAULT precision (f16x3), at sizes of several tiles: the schedules that only exist
+# there (fat dense-block launches, the Winograd forms of the FCN / DenseBlock coupling nets, fused tails) against the oracle.
+# HCF_FUZZ_SEEDS=n runs a longer campaign by hand.
+import os  # noqa: E402
+
+_NF = int(os.environ.get("HCF_FUZZ_SEEDS", "6"))
+
+
+@pytest.mark.parametrize("seed", range(_NF))
+def test_random_sr_configurations_f16x3_match_oracle(seed):
+    from hcflow_amd import HCFlowNet_SR
+    rng = np.random.default_rng(6000 + seed)
+    base = preset("SR_4X_tiny" if seed % 3 else "SR_8X_tiny")
+    K = [int(rng.integers(1, 5)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 3)), int(rng.integers(1, 3))))
+    cfg.validate()
+    p = make_params(cfg, 1500 + seed)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval().set_precision("f16x3")
+    g = torch.Generator().manual_seed(seed)
+    B = int(rng.integers(1, 4))
+    h, w = int(rng.integers(5, 24)) * 2, int(rng.integers(5, 30)) * 2
+    lr = torch.rand(B, 3, h, w, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.7 for s in eps_shapes(cfg, B, h, w)]
+    hr = torch.rand(B, 3, (h // 2) * cfg.scale, (w // 2) * cfg.scale, generator=g)          # NLL pass at half the linear size
+    lrh = torch.rand(B, 3, h // 2, w // 2, generator=g)
+    noise = torch.rand(hr.shape, generator=g)
+    want = O.sr_inverse(lr, p, cfg, 0.7, eps=eps, clamp=False)
+    lr_o, nll_o = O.sr_forward(hr, lrh, p, cfg, noise=noise)
+    with torch.no_grad():
+        got = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.7, eps=[e.cuda() for e in eps], clamp=False)
+        lr_g, nll_g = net(hr=hr.cuda(), lr=lrh.cuda(), reverse=False, noise=noise.cuda())
+    assert net.engine().fallback_count() == 0
+    sc = max(1.0, float(want.abs().max()))
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * sc, (K, after, B, h, w, float((got.cpu() - want).abs().max()))
+    assert float(((lr_g.cpu() - lr_o).abs() > 0.5 / 255).float().mean()) <= 1e-3      # quantised LR^: a level may flip on a boundary
+    assert abs(float(nll_g) - float(nll_o)) <= 2e-4 * max(1.0, abs(float(nll_o)) / 100)
+
+
+@pytest.mark.parametrize("seed", range(max(2, _NF // 2)))
+def test_random_rescaling_configurations_f16x3_match_oracle(seed):
+    from hcflow_amd import HCFlowNet_Rescaling
+    rng = np.random.default_rng(7000 + seed)
+    base = preset("Rescaling_4X_tiny")
+    K = [int(rng.integers(1, 5)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 3)), int(rng.integers(1, 3))))
+    cfg.validate()
+    p = make_params(cfg, 1900 + seed)
+    net = HCFlowNet_Rescaling(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval().set_precision("f16x3")
+    g = torch.Generator().manual_seed(seed)
+    B = int(rng.integers(1, 3))
+    h, w = int(rng.integers(5, 20)) * 2, int(rng.integers(5, 26)) * 2
+    hr = torch.rand(B, 3, h * 4, w * 4, generator=g)
+    lr = torch.rand(B, 3, h, w, generator=g)
+    eps = [torch.randn(s, generator=g) for s in eps_shapes(cfg, B, h, w)]
+    lo, z1o, z2o = O.rescale_forward(hr, p, cfg)
+    inv_o = O.rescale_inverse(lr, p, cfg, 1.0, eps=eps, clamp=False)
+    with torch.no_grad():
+        lg, z1g, z2g = net(hr=hr.cuda(), reverse=False)
+        inv_g = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=1.0, eps=[e.cuda() for e in eps], clamp=False)
+    assert net.engine().fallback_count() == 0
+    assert float(((lg.cpu() - lo).abs() > 0.5 / 255).float().mean()) <= 1e-3
+    assert float((z1g.cpu() - z1o).abs().max()) <= 1e-4 * max(1.0, float(z1o.abs().max()))
+    assert float((z2g.cpu() - z2o).abs().max()) <= 1e-4 * max(1.0, float(z2o.abs().max()))
+    assert float((inv_g.cpu() - inv_o).abs().max()) <= 1e-4 * max(1.0, float(inv_o.abs().max()))
