@@ -219,6 +219,7 @@ def test_random_rescaling_configurations_match_oracle(seed):
 import os  # noqa: E402
 
 _NF = int(os.environ.get("HCF_FUZZ_SEEDS", "6"))
+_SZ = int(os.environ.get("HCF_FUZZ_SIZE", "1"))            # multiplies the LR sizes (by hand: grids of several rounds)
 
 
 @pytest.mark.parametrize("seed", range(_NF))
@@ -239,7 +240,7 @@ def test_random_sr_configurations_f16x3_match_oracle(seed):
     net = net.to("cuda:0").eval().set_precision("f16x3")
     g = torch.Generator().manual_seed(seed)
     B = int(rng.integers(1, 4))
-    h, w = int(rng.integers(5, 24)) * 2, int(rng.integers(5, 30)) * 2
+    h, w = int(rng.integers(5, 24)) * 2 * _SZ, int(rng.integers(5, 30)) * 2 * _SZ
     lr = torch.rand(B, 3, h, w, generator=g)
     eps = [torch.randn(s, generator=g) * 0.7 for s in eps_shapes(cfg, B, h, w)]
     hr = torch.rand(B, 3, (h // 2) * cfg.scale, (w // 2) * cfg.scale, generator=g)          # NLL pass at half the linear size
@@ -275,7 +276,7 @@ def test_random_rescaling_configurations_f16x3_match_oracle(seed):
     net = net.to("cuda:0").eval().set_precision("f16x3")
     g = torch.Generator().manual_seed(seed)
     B = int(rng.integers(1, 3))
-    h, w = int(rng.integers(5, 20)) * 2, int(rng.integers(5, 26)) * 2
+    h, w = int(rng.integers(5, 20)) * 2 * _SZ, int(rng.integers(5, 26)) * 2 * _SZ
     hr = torch.rand(B, 3, h * 4, w * 4, generator=g)
     lr = torch.rand(B, 3, h, w, generator=g)
     eps = [torch.randn(s, generator=g) for s in eps_shapes(cfg, B, h, w)]
