@@ -105,7 +105,7 @@ int hcf_aux_conv2d(const float* x, int32_t cs_in, int32_t cin, int32_t B, int32_
       a.zeros = reinterpret_cast<const float*>(wk) + 16;
       int r2 = HCF_ERR_UNSUPPORTED;
       if ((cin & 15) == 0 && cin >= 64 && (nb == 32 || nb == 64)) {      // the dense 3x3 layers take the Winograd form
-        if (launch_repack_wino(r.w, cin, nb, wk + p.o_wino, st) == HCF_OK) r2 = launch_conv_wino(a, wk + p.o_wino, st);
+        if (launch_repack_wino(r.w, cin, nb, nb, wk + p.o_wino, st) == HCF_OK) r2 = launch_conv_wino(a, wk + p.o_wino, st);
       }
       if (r2 == HCF_ERR_UNSUPPORTED) {
         a.wpack = (const float*)(wk + p.o_pk16);

@@ -98,7 +98,7 @@ size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs
 size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
-int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st);   // pack rebuilt from device weights
+int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st);   // pack rebuilt from device weights
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------
 // dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)

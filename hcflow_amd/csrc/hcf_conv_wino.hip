@@ -39,7 +39,7 @@ size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out) {
 
 // Device-side rebuild of a Winograd pack from the PyTorch-layout weight in device memory (after an optimiser step): the same
 // arithmetic as wino::pack_weights_wino, one thread per (output channel, input channel).
-__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, uint16_t* __restrict__ pk) {
+__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk) {
 #pragma clang fp contract(off)
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= cin * cout) return;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restric
       const float x = (float)u;
       const _Float16 hi = (_Float16)x;       // (|x| 2^11 beyond the f16 range becomes inf: the conv raises the range flag)
       const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((float)((u - (double)(float)hi) * 2048.0));
-      const size_t o = (cout == 64)        // v4 layout: piece ((pos * 2 + ntile) * 2 + plane) of the chunk's 64
+      const size_t o = (cout_tile == 64)   // v4 layout: piece ((pos * 2 + ntile) * 2 + plane) of the chunk's 64
           ? (size_t)c * (wino::W4_BYTES / 2) + (size_t)(((xi * 4 + nu) * 2 + nt) * 2) * 512 + (size_t)h * 256 + (size_t)n * 8 + e
           : ((size_t)(nt * nchunk + c) * wino::W_BYTES) / 2 + (size_t)(((xi * 4 + nu) * 2 + 0) * 2 + h) * 256 + (size_t)n * 8 + e;
       pk[o] = __builtin_bit_cast(uint16_t, p0);
@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restric
     }
 }
 
-int launch_repack_wino(const float* w_dev, int cin, int cout, void* pk, hipStream_t st) {
-  if (!w_dev || !pk || cin < 16 || (cin & 15) || (cout & 31)) return HCF_ERR_ARG;
-  hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, w_dev, cin, cout,
+// cout_tile = the pack's width (32 / 64; > cout for the zero-padded tiles, whose extra rows stay as the host pack left them)
+int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st) {
+  if (!w_dev || !pk || cin < 16 || (cin & 15) || (cout_tile != 32 && cout_tile != 64) || cout < 1 || cout > cout_tile) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, w_dev, cin, cout, cout_tile,
                      reinterpret_cast<uint16_t*>(pk));
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }

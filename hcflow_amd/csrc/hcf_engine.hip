@@ -312,9 +312,21 @@ struct hcf_engine {
       if (pack_conv_weights_f16x3(w, cin, cout, cv.taps, srcs.data(), cv.nsrc, pk16, nc, np)) cv.wpack16 = upload(pk16);
     }
     cv.wpack_wino = nullptr;
+    cv.wino_ntile = 0;
     if (cv.wpack16 && cv.taps == 9 && wino_enabled) {
       std::vector<float> pkw;
       if (pack_conv_weights_wino(w, cin, cout, srcs.data(), cv.nsrc, pkw)) cv.wpack_wino = upload(pkw);
+      else if (wino_pad_ok && cout >= 8 && cout < 64 && cout != 32 && (cout & 3) == 0 && !getenv("HCF_NO_WINO_PAD")) {       // (A/B knob)
+        // other widths of the dense-block growth convs (the rescaling trunk's 16 channels): a zero-padded 32 / 64-channel tile
+        // (the prior heads, 12 / 24 output channels at K = 128, measured even-to-slower in that form and keep the direct kernel)
+        const int cout_t = cout < 32 ? 32 : 64;
+        std::vector<float> wp((size_t)cout_t * cin * 9, 0.f);
+        memcpy(wp.data(), w, (size_t)cout * cin * 9 * sizeof(float));
+        if (pack_conv_weights_wino(wp.data(), cin, cout_t, srcs.data(), cv.nsrc, pkw)) {
+          cv.wpack_wino = upload(pkw);
+          cv.wino_ntile = cout_t / 32;
+        }
+      }
     }
   }
 
@@ -525,9 +537,12 @@ struct hcf_engine {
     }
   }
 
+  bool wino_pad_ok = false;      // pack_conv may build a zero-padded Winograd tile for output widths other than 32 / 64
   void build_rdb(Rdb& r, const std::string& p, int nf, int gc) {
+    wino_pad_ok = true;
     for (int i = 0; i < 4; ++i)
       build_conv(r.c[i], p + ".conv" + std::to_string(i + 1), nf + i * gc, gc, srcs2(nf, i * gc), ACT_LRELU);
+    wino_pad_ok = false;
     build_conv(r.c[4], p + ".conv5", nf + 4 * gc, nf, srcs2(nf, 4 * gc), ACT_NONE);
     r.fat[0] = r.fat[1] = false;
     static const bool no_fat = getenv("HCF_NO_FAT") != nullptr;          // A/B knob, read once
