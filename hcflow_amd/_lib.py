@@ -48,6 +48,7 @@ class hcf_config(C.Structure):
         ("perm", C.c_int32), ("coupling", C.c_int32), ("nn_module", C.c_int32), ("hidden", C.c_int32),
         ("c_perm", C.c_int32), ("c_coupling", C.c_int32), ("c_nn_module", C.c_int32), ("c_hidden", C.c_int32),
         ("rrdb_nb", C.c_int32 * 2), ("rrdb_nf", C.c_int32), ("rrdb_gc", C.c_int32),
+        ("lu_decomposed", C.c_int32),
     ]
 
 
@@ -166,6 +167,7 @@ def make_config(cfg) -> hcf_config:
                                                          nn[cfg.c_nn_module], cfg.c_hidden)
     c.rrdb_nb[0], c.rrdb_nb[1] = cfg.rrdb_nb
     c.rrdb_nf, c.rrdb_gc = cfg.rrdb_nf, cfg.rrdb_gc
+    c.lu_decomposed = 1 if getattr(cfg, "lu", False) else 0
     return c
 
 

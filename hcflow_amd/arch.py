@@ -52,12 +52,29 @@ class ActNorm2d(nn.Module):
 
 
 class InvertibleConv1x1(nn.Module):
-    """Permutations.InvertibleConv1x1, LU_decomposed=False (Permutations.py:33-40): random orthogonal init."""
+    """Parameter holder of Permutations.InvertibleConv1x1 (Permutations.py:33-58): random orthogonal init; with
+    ``LU_decomposed`` the factors of W = P (L o l_mask + I) (U o l_mask^T + diag(sign_s exp(log_s))) -- parameters l, log_s, u,
+    buffers p, sign_s (fixed), plain attributes l_mask, eye -- under the reference's names. The engine composes W / W^-1 and
+    uses dlogdet = sum(log_s) * pixels (Permutations.py:78-92; hcf_engine.hip build_step)."""
 
-    def __init__(self, num_channels):
+    def __init__(self, num_channels, LU_decomposed=False):
         super().__init__()
-        w_init = np.linalg.qr(np.random.randn(num_channels, num_channels))[0].astype(np.float32)
-        self.weight = nn.Parameter(torch.from_numpy(w_init))
+        w_shape = [num_channels, num_channels]
+        w_init = np.linalg.qr(np.random.randn(*w_shape))[0].astype(np.float32)
+        if not LU_decomposed:
+            self.weight = nn.Parameter(torch.from_numpy(w_init))
+        else:
+            P, L, U = torch.linalg.lu(torch.from_numpy(w_init).double())     # w = P L U, partial pivoting (scipy.linalg.lu there)
+            s = torch.diagonal(U)
+            self.register_buffer("p", P.float())
+            self.register_buffer("sign_s", torch.sign(s).float())
+            self.l = nn.Parameter(L.float())
+            self.log_s = nn.Parameter(torch.log(torch.abs(s)).float())
+            self.u = nn.Parameter(torch.triu(U, 1).float())
+            self.l_mask = torch.tril(torch.ones(*w_shape), -1)
+            self.eye = torch.eye(*w_shape)
+        self.w_shape = w_shape
+        self.LU = LU_decomposed
 
 
 class Conv2d(nn.Module):
@@ -148,11 +165,11 @@ class AffineCoupling(nn.Module):
 class FlowStep(nn.Module):
     """FlowStep (FlowStep.py:8-38): actnorm, permute, affine."""
 
-    def __init__(self, C, cond, perm, coupling, nn_module, hidden, lr_vs_others=True):
+    def __init__(self, C, cond, perm, coupling, nn_module, hidden, lr_vs_others=True, LU_decomposed=False):
         super().__init__()
         self.actnorm = ActNorm2d(C)
         if perm == "invconv":
-            self.permute = InvertibleConv1x1(C)
+            self.permute = InvertibleConv1x1(C, LU_decomposed=LU_decomposed)
         else:
             self.permute = None
         self.affine = AffineCoupling(C, cond, coupling, nn_module, hidden, lr_vs_others)
@@ -198,7 +215,7 @@ class ConditionalFlow(nn.Module):
         self.RRDB_trunk1 = nn.Sequential(*[RRDB(cfg.rrdb_nf, cfg.rrdb_gc) for _ in range(cfg.rrdb_nb[1])])
         self.trunk_conv1 = PlainConv(cfg.rrdb_nf, cfg.rrdb_nf, init="default")
         self.additional_flow_steps = nn.ModuleList(
-            [FlowStep(C - ns, cfg.cond_ch, cfg.c_perm, cfg.c_coupling, cfg.c_nn_module, cfg.c_hidden)
+            [FlowStep(C - ns, cfg.cond_ch, cfg.c_perm, cfg.c_coupling, cfg.c_nn_module, cfg.c_hidden, LU_decomposed=cfg.lu)
              for _ in range(cfg.after[level])])
         self.f = Conv2dZeros(cfg.cond_ch, (C - ns) * 2)
 
@@ -218,7 +235,7 @@ class FlowNet(nn.Module):
             self.output_shapes.append([-1, C, H, W])
             for k in range(cfg.K[level] - cfg.after[level]):
                 lrv = True if cfg.sr else (k % 2 == 0)
-                self.layers.append(FlowStep(C, 0, cfg.perm, cfg.coupling, cfg.nn_module, cfg.hidden, lrv))
+                self.layers.append(FlowStep(C, 0, cfg.perm, cfg.coupling, cfg.nn_module, cfg.hidden, lrv, LU_decomposed=cfg.lu))
                 self.output_shapes.append([-1, C, H, W])
             ns = cfg.split_channels(level)
             self.layers.append(Split(ns, level))

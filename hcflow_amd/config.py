@@ -51,6 +51,10 @@ class NetConfig:
     rrdb_nb: Tuple[int, int] = (5, 5)
     rrdb_nf: int = 64
     rrdb_gc: int = 32
+    # FlowStep(LU_decomposed=...) -> Permutations.InvertibleConv1x1(LU_decomposed=...) (FlowStep.py:9-10,20;
+    # Permutations.py:41-57): W = P (L o mask + I) (U o mask^T + diag(sign_s exp(log_s))). No shipped yml sets it (FlowNet never
+    # passes the argument); read from network_G.flowDownsampler.LU_decomposed. Applies to every invconv step of the net.
+    lu: bool = False
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -125,6 +129,7 @@ class NetConfig:
             c_hidden=opt_get(so, ["hidden_channels"], 64),
             rrdb_nb=(int(rrdb_nb[0]), int(rrdb_nb[1])),
             rrdb_nf=opt_get(so, ["RRDB_nf"], 64), rrdb_gc=opt_get(so, ["RRDB_gc"], 32),
+            lu=bool(opt_get(fd, ["LU_decomposed"], False)),
         )
         cfg.validate()
         return cfg
@@ -167,6 +172,8 @@ class NetConfig:
                 },
             },
         }
+        if self.lu:
+            opt["network_G"]["flowDownsampler"]["LU_decomposed"] = True
         if self.sr:
             opt["quant"] = self.quant
         else:
@@ -202,6 +209,13 @@ def preset(name: str) -> NetConfig:
         return NetConfig(kind="Rescaling", scale=4, quant=256.0, L=2, K=[5, 5, 5], after=[2, 2],
                          squeeze="haar", perm="none", coupling="Affine3shift",
                          nn_module="DenseBlock", hidden=32, rrdb_nb=(1, 1), rrdb_gc=16)
+    # LU-decomposed invertible 1x1 convs (Permutations.py:41-57) in every flow step: no shipped yml selects them
+    if name in ("SR_4X_tiny_LU", "SR_8X_tiny_LU", "Rescaling_4X_tiny_LU", "SR_DF2K_4X_LU"):
+        c = preset(name[:-3])
+        c.lu = True
+        if c.perm == "none":           # the rescaling yml has no permutation in its main steps: give the LU variant one
+            c.perm = "invconv"
+        return c
     # narrow variants (RRDB_nf 8, hidden 8) for the checkpoint fixtures: a whole state dict in a few hundred KB
     if name == "SR_4X_micro":
         return NetConfig(kind="SR", scale=4, quant=64.0, L=2, K=[3, 3, 3], after=[1, 1], hidden=8, c_hidden=8,
@@ -257,11 +271,19 @@ def coupling_io(C: int, cond: int, coupling: str, lr_vs_others: bool) -> Tuple[i
 
 
 def _flowstep(out: List[ParamSpec], p: str, C: int, cond: int, perm: str, coupling: str,
-              nn_module: str, hid: int, lr_vs_others: bool = True):
+              nn_module: str, hid: int, lr_vs_others: bool = True, lu: bool = False):
     """FlowStep (FlowStep.py:8-38): actnorm, permute, affine."""
     out.append((p + ".actnorm.bias", (1, C, 1, 1), "an_bias"))
     out.append((p + ".actnorm.logs", (1, C, 1, 1), "an_logs"))
-    if perm == "invconv":
+    if perm == "invconv" and lu:
+        # Permutations.py:51-55: parameters l, log_s, u, then the buffers p, sign_s (state_dict lists a module's parameters
+        # before its buffers); l_mask / eye are plain attributes and never enter the state dict
+        out.append((p + ".permute.l", (C, C), "lu_l"))
+        out.append((p + ".permute.log_s", (C,), "lu_log_s"))
+        out.append((p + ".permute.u", (C, C), "lu_u"))
+        out.append((p + ".permute.p", (C, C), "lu_p"))
+        out.append((p + ".permute.sign_s", (C,), "lu_sign_s"))
+    elif perm == "invconv":
         out.append((p + ".permute.weight", (C, C), "invconv"))
     fin, fout = coupling_io(C, cond, coupling, lr_vs_others)
     if nn_module == "FCN":
@@ -290,7 +312,7 @@ def _condflow(out: List[ParamSpec], p: str, cfg: NetConfig, level: int):
     _conv(out, p + ".trunk_conv1", cfg.rrdb_nf, cfg.rrdb_nf, 3)
     for k in range(cfg.after[level]):
         _flowstep(out, "%s.additional_flow_steps.%d" % (p, k), C - ns, cfg.cond_ch,
-                  cfg.c_perm, cfg.c_coupling, cfg.c_nn_module, cfg.c_hidden)
+                  cfg.c_perm, cfg.c_coupling, cfg.c_nn_module, cfg.c_hidden, lu=cfg.lu)
     out.append((p + ".f.weight", ((C - ns) * 2, cfg.cond_ch, 3, 3), "zeros_w"))
     out.append((p + ".f.bias", ((C - ns) * 2,), "zeros_b"))
     out.append((p + ".f.logs", ((C - ns) * 2, 1, 1), "zeros_logs"))
@@ -329,7 +351,7 @@ def param_spec(cfg: NetConfig) -> List[ParamSpec]:
             out.append((p + ".haar_weights", (4 * ent["C_in"], 1, 2, 2), "haar"))
         elif ent["type"] == "flowstep":
             _flowstep(out, p, ent["C"], 0, cfg.perm, cfg.coupling, cfg.nn_module, cfg.hidden,
-                      ent["lr_vs_others"])
+                      ent["lr_vs_others"], lu=cfg.lu)
     for level in range(cfg.L):
         _condflow(out, "flow.level%d_condFlow" % level, cfg, level)
     return out

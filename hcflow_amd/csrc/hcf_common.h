@@ -253,6 +253,11 @@ int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, i
 int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st);      // out += alpha * in
 int launch_add_const(float* p, size_t n, float v, hipStream_t st);                             // p[i] += v
 int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st);              // y += alpha * x
+// LU-decomposed invertible 1x1 conv (Permutations.py:78-86: W = P L U', L = l o mask + I, U' = u o mask^T + diag(sign_s e^log_s)):
+// chain rule of dL/dW into the factors, A = P^T dW:  dl += strict_lower(A U'^T),  du += strict_upper(L^T A),
+// dlog_s[i] += (L^T A)[i][i] * U'[i][i].  All matrices [C][C] row-major, C <= 48; one block.
+struct LuChainArgs { const float *dW, *P, *L, *U; float *dl, *du, *dlog_s; int C; };
+int launch_lu_chain(const LuChainArgs& a, hipStream_t st);
 
 // ---- Gaussian prior / misc elementwise -------------------------------------------------------
 struct GaussArgs {

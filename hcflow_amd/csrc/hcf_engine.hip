@@ -78,6 +78,12 @@ struct Step {
   float *mat_fwdT = nullptr;        // training: W^T padded [cmax][cmax] (gza = W^T gzb)
   float *winvT = nullptr;           // training: W^-T, [C][C] unpadded (d slogdet / dW)
   float *mat_invT = nullptr;        // training: (W^-1)^T padded [cmax][cmax] (reverse path: gzc = W^-T gy)
+  // LU-decomposed invertible conv (Permutations.py:41-57,78-92): the engine composes W = P L U' on the host (fp64, rounded to
+  // fp32) and runs the same kernels; lad = sum(log_s). Training: dL/dW is accumulated in lu_dw and chained into l / u / log_s
+  // by lu_chain_kernel (hcf_train.hip) from the device copies of P, L = l o mask + I, U' = u o mask^T + diag(sign_s e^log_s).
+  bool lu = false;
+  std::string lu_pre;               // "....permute"
+  float *lu_P = nullptr, *lu_L = nullptr, *lu_U = nullptr, *lu_dw = nullptr;   // device [C][C] each
 };
 
 // fat = the "fat launch" form of conv3 / conv4 (profiles/r03_notes.md): c34 = conv3 + the [x, x1, x2] part of conv4 as ONE
@@ -411,13 +417,28 @@ struct hcf_engine {
     s.hid = hid;
     s.fcn = (nn_module == HCF_NN_FCN);
     s.an_key = p + ".actnorm";
-    s.wkey = (perm == HCF_PERM_INVCONV) ? p + ".permute.weight" : std::string();
+    s.lu = (perm == HCF_PERM_INVCONV) && cfg.lu_decomposed != 0;
+    s.lu_pre = p + ".permute";
+    s.wkey = (perm == HCF_PERM_INVCONV && !s.lu) ? p + ".permute.weight" : std::string();
     if (s.cmax < 0) { fail(HCF_ERR_UNSUPPORTED, "flow step with more than 48 channels"); return; }
     const float* ab = P(p + ".actnorm.bias", {1, C, 1, 1});
     const float* al = P(p + ".actnorm.logs", {1, C, 1, 1});
     const float* W = nullptr;
     s.has_mat = (perm == HCF_PERM_INVCONV);
-    if (s.has_mat) W = P(p + ".permute.weight", {C, C});
+    std::vector<float> lu_w, lu_l, lu_u;
+    double lu_sumlogs = 0;
+    if (s.lu) {
+      // state_dict order of the module: parameters l, log_s, u, then the buffers p, sign_s (Permutations.py:51-55)
+      const float* pl = P(s.lu_pre + ".l", {C, C});
+      const float* ps = P(s.lu_pre + ".log_s", {C});
+      const float* pu = P(s.lu_pre + ".u", {C, C});
+      const float* pp = P(s.lu_pre + ".p", {C, C});
+      const float* pg = P(s.lu_pre + ".sign_s", {C});
+      if (!spec_mode && rc == HCF_OK) {
+        compose_lu(pl, ps, pu, pp, pg, C, lu_w, lu_l, lu_u, lu_sumlogs);
+        W = lu_w.data();
+      }
+    } else if (s.has_mat) W = P(p + ".permute.weight", {C, C});
     // coupling geometry (AffineCouplings.py:18-19, 101-106)
     int z1_n;
     if (coupling == HCF_COUPLING_AFFINE) {
@@ -532,9 +553,50 @@ struct hcf_engine {
         s.winvT = upload(it);
         s.mat_invT = upload(itp);
       }
+      if (s.lu) {
+        lad = lu_sumlogs;                              // dlogdet = sum(log_s) * pixels (Permutations.py:84)
+        std::vector<float> pm(s_lu_p(s), s_lu_p(s) + (size_t)C * C);
+        s.lu_P = upload(pm);
+        s.lu_L = upload(lu_l);
+        s.lu_U = upload(lu_u);
+        s.lu_dw = upload(std::vector<float>((size_t)C * C, 0.f));
+      }
       s.lad = lad;
       s.ld_const += lad;
     }
+  }
+  const float* s_lu_p(const Step& s) { return params[s.lu_pre + ".p"].data.data(); }
+
+  // W = P (L o mask + I) (U o mask^T + diag(sign_s exp(log_s))) (Permutations.py:78-86), composed in fp64 and rounded once;
+  // Lc / Uc = the two triangular factors as the chain rule of the training path needs them; sumlogs = sum(log_s)
+  static void compose_lu(const float* l, const float* log_s, const float* u, const float* p, const float* sign_s, int C,
+                         std::vector<float>& W, std::vector<float>& Lc, std::vector<float>& Uc, double& sumlogs) {
+    std::vector<double> L((size_t)C * C, 0.0), U((size_t)C * C, 0.0), LU((size_t)C * C, 0.0);
+    sumlogs = 0;
+    for (int i = 0; i < C; ++i) {
+      for (int j = 0; j < C; ++j) {
+        L[(size_t)i * C + j] = j < i ? (double)l[(size_t)i * C + j] : (i == j ? 1.0 : 0.0);
+        U[(size_t)i * C + j] = j > i ? (double)u[(size_t)i * C + j] : 0.0;
+      }
+      U[(size_t)i * C + i] = (double)(sign_s[i] * expf(log_s[i]));       // fp32 exp, as torch.exp on the fp32 parameter
+      sumlogs += (double)log_s[i];
+    }
+    for (int i = 0; i < C; ++i)
+      for (int k = 0; k <= i; ++k) {
+        const double a = L[(size_t)i * C + k];
+        if (a == 0.0) continue;
+        for (int j = k; j < C; ++j) LU[(size_t)i * C + j] += a * U[(size_t)k * C + j];
+      }
+    W.assign((size_t)C * C, 0.f);
+    for (int i = 0; i < C; ++i)
+      for (int j = 0; j < C; ++j) {
+        double acc = 0;
+        for (int k = 0; k < C; ++k) acc += (double)p[(size_t)i * C + k] * LU[(size_t)k * C + j];
+        W[(size_t)i * C + j] = (float)acc;
+      }
+    Lc.resize((size_t)C * C);
+    Uc.resize((size_t)C * C);
+    for (size_t i = 0; i < (size_t)C * C; ++i) { Lc[i] = (float)L[i]; Uc[i] = (float)U[i]; }
   }
 
   bool wino_pad_ok = false;      // pack_conv may build a zero-padded Winograd tile for output widths other than 32 / 64

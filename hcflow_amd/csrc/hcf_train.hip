@@ -458,4 +458,38 @@ int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st)
   HCF_RET_T();
 }
 
+// ---- LU-decomposed invertible 1x1 conv: dL/dW -> dl, du, dlog_s (see hcf_common.h) --------------------------------------
+__global__ __launch_bounds__(256) void lu_chain_kernel(const LuChainArgs a) {
+  constexpr int MAXC = 48;
+  __shared__ float sG[MAXC * MAXC], sA[MAXC * MAXC], sP[MAXC * MAXC], sL[MAXC * MAXC], sU[MAXC * MAXC];
+  const int C = a.C, n = C * C, tid = threadIdx.x;
+  for (int e = tid; e < n; e += 256) { sG[e] = a.dW[e]; sP[e] = a.P[e]; sL[e] = a.L[e]; sU[e] = a.U[e]; }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {             // A = P^T G
+    const int i = e / C, j = e % C;
+    float acc = 0.f;
+    for (int k = 0; k < C; ++k) acc = fmaf(sP[k * C + i], sG[k * C + j], acc);
+    sA[e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const int i = e / C, j = e % C;
+    if (j < i) {                                   // dL = A U'^T, strictly lower part -> l
+      float acc = 0.f;
+      for (int k = 0; k < C; ++k) acc = fmaf(sA[i * C + k], sU[j * C + k], acc);
+      a.dl[e] += acc;
+    } else {                                       // dU' = L^T A, strictly upper part -> u, diagonal -> log_s
+      float acc = 0.f;
+      for (int k = 0; k < C; ++k) acc = fmaf(sL[k * C + i], sA[k * C + j], acc);
+      if (j > i) a.du[e] += acc;
+      else a.dlog_s[i] += acc * sU[i * C + i];
+    }
+  }
+}
+int launch_lu_chain(const LuChainArgs& a, hipStream_t st) {
+  if (a.C < 1 || a.C > 48) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(lu_chain_kernel, dim3(1), dim3(256), 0, st, a);
+  HCF_RET_T();
+}
+
 }  // namespace hcf

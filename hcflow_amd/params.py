@@ -36,10 +36,28 @@ def _orthogonal(C: int, gen: torch.Generator) -> torch.Tensor:
     return (q * d.unsqueeze(0)).to(torch.float32).contiguous()
 
 
+def _lu_factors(C: int, gen: torch.Generator) -> Dict[str, torch.Tensor]:
+    """The five tensors of an LU-decomposed InvertibleConv1x1 (Permutations.py:41-57) for a seeded well-conditioned W:
+    W = P L (U + diag(sign_s exp(log_s))), partial pivoting in float64 (what scipy.linalg.lu does there), plus a small
+    perturbation of l / u / log_s so that the stored factors are not exactly those of an orthogonal matrix."""
+    w = _orthogonal(C, gen).double()
+    P, L, U = torch.linalg.lu(w)                       # w = P @ L @ U
+    s = torch.diagonal(U)
+    out = {
+        "lu_p": P,
+        "lu_sign_s": torch.sign(s),
+        "lu_log_s": torch.log(torch.abs(s)) + 0.02 * torch.randn(C, generator=gen, dtype=torch.float64),
+        "lu_l": L + torch.tril(0.02 * torch.randn(C, C, generator=gen, dtype=torch.float64), -1),
+        "lu_u": torch.triu(U, 1) + torch.triu(0.02 * torch.randn(C, C, generator=gen, dtype=torch.float64), 1),
+    }
+    return {k: v.to(torch.float32).contiguous() for k, v in out.items()}
+
+
 def make_params(cfg: NetConfig, seed: int = 1234) -> Dict[str, torch.Tensor]:
     gen = torch.Generator(device="cpu")
     gen.manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
+    lu = None
     for key, shape, kind in param_spec(cfg):
         if kind == "conv_w":
             cout, cin, kh, kw = shape
@@ -63,6 +81,10 @@ def make_params(cfg: NetConfig, seed: int = 1234) -> Dict[str, torch.Tensor]:
             t = torch.randn(shape, generator=gen) * 0.03
         elif kind == "invconv":
             t = _orthogonal(shape[0], gen)
+        elif kind.startswith("lu_"):
+            if kind == "lu_l":                       # first of a step's five LU tensors in spec order
+                lu = _lu_factors(shape[0], gen)
+            t = lu[kind]
         elif kind == "haar":
             # HaarDownsampling.haar_weights (Basic.py:455-468): frozen +-1 pattern
             w = torch.ones(4, 1, 2, 2)

@@ -79,6 +79,9 @@ typedef struct hcf_config {
   int32_t c_perm, c_coupling, c_nn_module, c_hidden;  /* conditional (splitOff) flow steps */
   int32_t rrdb_nb[2];
   int32_t rrdb_nf, rrdb_gc;
+  int32_t lu_decomposed;    /* FlowStep(LU_decomposed=...) (FlowStep.py:9-10,20): every invertible 1x1 conv holds the factors
+                             * l, log_s, u (parameters) and p, sign_s (buffers) of W = P (L o mask + I) (U o mask^T + diag(sign_s
+                             * exp(log_s))) instead of `weight` (Permutations.py:41-57,78-92); dlogdet = sum(log_s) * pixels */
 } hcf_config;
 
 /* ---- life cycle -------------------------------------------------------------------------- */

@@ -181,6 +181,26 @@ def invconv_inverse(x, W):
     return F.conv2d(x, Winv.view(C, C, 1, 1))
 
 
+def invconv_lu_weight(p, pre: str, reverse: bool):
+    """InvertibleConv1x1.get_weight, LU_decomposed branch (Permutations.py:78-92): returns (weight [C, C], sum(log_s)).
+    l = self.l * l_mask + eye; u = self.u * l_mask^T + diag(sign_s * exp(log_s)); forward w = p @ (l @ u); reverse
+    w = inverse(u.double()).float() @ (inverse(l.double()).float() @ p.inverse())."""
+    l_, u_, log_s = p[pre + ".l"], p[pre + ".u"], p[pre + ".log_s"]
+    perm, sign_s = p[pre + ".p"], p[pre + ".sign_s"]
+    C = l_.shape[0]
+    l_mask = torch.tril(torch.ones(C, C, dtype=l_.dtype), -1)
+    eye = torch.eye(C, dtype=l_.dtype)
+    l = l_ * l_mask + eye
+    u = u_ * l_mask.transpose(0, 1).contiguous() + torch.diag(sign_s * torch.exp(log_s))
+    if not reverse:
+        w = torch.matmul(perm, torch.matmul(l, u))
+    else:
+        l = torch.inverse(l.double()).float()
+        u = torch.inverse(u.double()).float()
+        w = torch.matmul(u, torch.matmul(l, perm.inverse()))
+    return w, torch.sum(log_s)
+
+
 def logscale_of(scale):
     """FrEIA-style soft clamp (AffineCouplings.py:53,83): 0.318 * atan(2 * scale)."""
     return 0.318 * torch.atan(2 * scale)
@@ -282,7 +302,12 @@ def flowstep_forward(z, u, logdet, p: P, pre: str, perm: str, kind: str, nn_modu
     z = actnorm_forward(z, p[pre + ".actnorm.bias"], p[pre + ".actnorm.logs"])
     if logdet is not None:
         logdet = logdet + actnorm_logdet(p[pre + ".actnorm.logs"], pix)
-    if perm == "invconv":
+    if perm == "invconv" and (pre + ".permute.l") in p:      # LU_decomposed=True (Permutations.py:78-92)
+        Wm, sum_log_s = invconv_lu_weight(p, pre + ".permute", reverse=False)
+        z = invconv_forward(z, Wm)
+        if logdet is not None:
+            logdet = logdet + sum_log_s * pix
+    elif perm == "invconv":
         Wm = p[pre + ".permute.weight"]
         z = invconv_forward(z, Wm)
         if logdet is not None:
@@ -296,7 +321,10 @@ def flowstep_forward(z, u, logdet, p: P, pre: str, perm: str, kind: str, nn_modu
 def flowstep_inverse(z, u, p: P, pre: str, perm: str, kind: str, nn_module: str, lr_vs_others=True):
     """FlowStep.reverse_flow (FlowStep.py:53-64): coupling^-1, permute^-1, actnorm^-1."""
     z, _ = coupling(z, u, p, pre + ".affine", kind, nn_module, lr_vs_others, reverse=True)
-    if perm == "invconv":
+    if perm == "invconv" and (pre + ".permute.l") in p:
+        Wi, _ = invconv_lu_weight(p, pre + ".permute", reverse=True)
+        z = invconv_forward(z, Wi)
+    elif perm == "invconv":
         z = invconv_inverse(z, p[pre + ".permute.weight"])
     return actnorm_inverse(z, p[pre + ".actnorm.bias"], p[pre + ".actnorm.logs"])
 

@@ -70,11 +70,35 @@ class Capture:
         torch.normal, torch.rand = self._n, self._r
 
 
+class ReferenceLU:
+    """The reference's FlowNets never pass ``LU_decomposed`` to FlowStep (FlowStep.py:9-10,20), so no yml can switch the
+    LU-decomposed InvertibleConv1x1 (Permutations.py:41-57) on. For the LU fixtures the DEFAULT of that constructor argument
+    is flipped while the reference net is built -- the reference's own FlowStep / InvertibleConv1x1 code then runs unchanged."""
+
+    def __enter__(self):
+        from models.modules import FlowStep as FS
+        self.fn = FS.FlowStep.__init__
+        self.old = self.fn.__defaults__
+        names = self.fn.__code__.co_varnames[:self.fn.__code__.co_argcount]
+        i = names.index("LU_decomposed") - (len(names) - len(self.old))
+        assert self.old[i] is False
+        self.fn.__defaults__ = self.old[:i] + (True,) + self.old[i + 1:]
+        return self
+
+    def __exit__(self, *exc):
+        self.fn.__defaults__ = self.old
+
+
 def build(ref_cls, cfg: NetConfig, seed: int):
     opt = cfg.to_opt()
     torch.manual_seed(0)
     np.random.seed(0)
-    net = ref_cls(opt=opt, step=0)
+    if cfg.lu:
+        with ReferenceLU():
+            net = ref_cls(opt=opt, step=0)
+        assert any(k.endswith(".permute.log_s") for k in net.state_dict())
+    else:
+        net = ref_cls(opt=opt, step=0)
     params = make_params(cfg, seed)
     sd = net.state_dict()
     assert list(sd.keys()) == [k for k, _, _ in param_spec(cfg)], "state_dict key ORDER mismatch"
@@ -194,6 +218,13 @@ def gen_aninit_fixture(name, preset_name, ref_sr, ref_rs, B, h, w, seed):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def spec_tensors(net, cfg):
+    """(key, tensor) of the reference net in param_spec (= state_dict) order: parameters with their .grad, buffers as they are."""
+    prm = dict(net.named_parameters())
+    buf = dict(net.named_buffers())
+    return [(k, prm[k] if k in prm else buf[k]) for k, _, _ in param_spec(cfg)]
+
+
 def grad_digest(g, i):
     """Three numbers per gradient tensor: l2 norm, sum, and a seeded random projection."""
     g = np.asarray(g, dtype=np.float64).reshape(-1)
@@ -218,14 +249,14 @@ def gen_grad_fixture(name, preset_name, ref_sr, B, h, w, seed):
     dg = param_digest(params)
     out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
     dig, nfull = [], 0
-    for i, (k, prm) in enumerate(net.named_parameters()):
-        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+    for i, (k, prm) in enumerate(spec_tensors(net, cfg)):     # state-dict order; buffers (LU p / sign_s) carry zero gradients
+        gr = np.zeros(tuple(prm.shape), np.float32) if getattr(prm, "grad", None) is None else np_(prm.grad)
         dig.append(grad_digest(gr, i))
         if gr.size <= 2304:
             out["g_%d" % i] = gr
             nfull += 1
     keys = [k for k, _ in net.named_parameters()]
-    assert keys == [k for k, _, _ in param_spec(cfg)]
+    assert keys == [k for k, _, kind in param_spec(cfg) if kind not in ("lu_p", "lu_sign_s")]
     out["gdigest"] = np.array(dig, dtype=np.float64)
     print("  %s nll %.6f: %d tensors, %d stored in full, |g| range [%.3e, %.3e]" % (
         name, float(nll), len(dig), nfull, min(d[0] for d in dig), max(d[0] for d in dig)))
@@ -255,8 +286,8 @@ def gen_rgrad_fixture(name, preset_name, ref_sr, B, h, w, seed, tau):
     dg = param_digest(params)
     out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
     dig, nfull = [], 0
-    for i, (k, prm) in enumerate(net.named_parameters()):
-        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+    for i, (k, prm) in enumerate(spec_tensors(net, cfg)):     # state-dict order; buffers (LU p / sign_s) carry zero gradients
+        gr = np.zeros(tuple(prm.shape), np.float32) if getattr(prm, "grad", None) is None else np_(prm.grad)
         dig.append(grad_digest(gr, i))
         if gr.size <= 2304:
             out["g_%d" % i] = gr
@@ -342,8 +373,8 @@ def gen_rescale_grad_fixture(name, preset_name, ref_rs, B, h, w, seed):
     dg = param_digest(params)
     out["digest"] = np.array([dg["n"], dg["sum"], dg["sumsq"], dg["probe"]], dtype=np.float64)
     dig, nfull = [], 0
-    for i, (k, prm) in enumerate(net.named_parameters()):
-        gr = np.zeros(tuple(prm.shape), np.float32) if prm.grad is None else np_(prm.grad)
+    for i, (k, prm) in enumerate(spec_tensors(net, cfg)):     # state-dict order; buffers (LU p / sign_s) carry zero gradients
+        gr = np.zeros(tuple(prm.shape), np.float32) if getattr(prm, "grad", None) is None else np_(prm.grad)
         dig.append(grad_digest(gr, i))
         if gr.size <= 2304:
             out["g_%d" % i] = gr
@@ -704,6 +735,17 @@ def main():
         gen_real_net_fixture("net_rescale_real", "Rescaling_DF2K_4X", ref_sr, ref_rs, img_tensor(im["butterfly_lr"]),
                              img_tensor(im["butterfly_hr"]), seed=75, taus=(0.0, 1.0), images="butterfly")
         if only == "real":
+            return
+    if only in ("all", "lu"):
+        # LU-decomposed invertible 1x1 convs (Permutations.py:41-57,78-92) in every flow step: inverse / NLL / rescaling fixtures,
+        # the NLL-step gradients of l / log_s / u, and the reverse-path gradients
+        gen_net_fixture("net_sr4_tiny_lu", "SR_4X_tiny_LU", ref_sr, ref_rs, B=2, h=10, w=12, seed=91)
+        gen_net_fixture("net_sr8_tiny_lu", "SR_8X_tiny_LU", ref_sr, ref_rs, B=2, h=5, w=6, seed=92)
+        gen_net_fixture("net_rescale_tiny_lu", "Rescaling_4X_tiny_LU", ref_sr, ref_rs, B=2, h=10, w=12, seed=93, taus=(0.0, 1.0))
+        gen_grad_fixture("grad_sr4_tiny_lu", "SR_4X_tiny_LU", ref_sr, B=2, h=10, w=12, seed=94)
+        gen_rgrad_fixture("rgrad_sr4_tiny_lu", "SR_4X_tiny_LU", ref_sr, B=2, h=10, w=12, seed=95, tau=0.7)
+        gen_rescale_grad_fixture("grad_rescale_tiny_lu", "Rescaling_4X_tiny_LU", ref_rs, B=2, h=10, w=12, seed=96)
+        if only == "lu":
             return
     if only in ("all", "gan"):
         gen_gan_fixture()

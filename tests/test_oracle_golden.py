@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import hcflow_oracle as O
-from tests.util import load_golden, params_for, t, maxdiff
+from tests.util import load_golden, params_for, t, maxdiff, trainable
 
 
 def test_index_ops_bit_exact():
@@ -78,8 +78,9 @@ def test_rescaling_ops():
     assert maxdiff(O.cond_features(t(g["cf_in"]), p, "flow.level1_condFlow", cfg), g["cf_out"]) <= 1e-5
 
 
-NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full"]
-NETS_RS = ["net_rescale_tiny", "net_rescale_full"]
+# *_lu: every invertible 1x1 conv LU-decomposed (Permutations.py:41-57,78-92; make_golden.py ReferenceLU)
+NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full", "net_sr4_tiny_lu", "net_sr8_tiny_lu"]
+NETS_RS = ["net_rescale_tiny", "net_rescale_full", "net_rescale_tiny_lu"]
 
 
 def _eps(g, pre):
@@ -176,7 +177,7 @@ def test_actnorm_data_init_pass(name):
         assert maxdiff(ip[k + ".logs"].reshape(-1), g["an_logs_%d" % i]) <= 1e-5, k
 
 
-GRADS = ["grad_sr4_tiny", "grad_sr8_tiny"]
+GRADS = ["grad_sr4_tiny", "grad_sr8_tiny", "grad_sr4_tiny_lu"]
 
 
 def grad_digest(g, i):
@@ -212,7 +213,7 @@ def test_nll_gradients_match_reference(name):
     HCFlow_SR_model.optimize_parameters, :195-199), incl. the straight-through Quant (Basic.py:186-196)."""
     g = load_golden(name)
     cfg, p = params_for(g)
-    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    q = trainable(p, cfg)
     lr_hat, nll = O.sr_forward(t(g["hr"]), t(g["lr"]), q, cfg, noise=t(g["fwd_noise"]))
     assert abs(float(nll.detach()) - float(g["fwd_nll"])) <= 2e-4 * max(1.0, abs(float(g["fwd_nll"])) / 100)
     nll.backward()
@@ -221,7 +222,7 @@ def test_nll_gradients_match_reference(name):
     check_grads_against_fixture(g, grads)
 
 
-RGRADS = ["rgrad_sr4_tiny", "rgrad_sr8_tiny"]
+RGRADS = ["rgrad_sr4_tiny", "rgrad_sr8_tiny", "rgrad_sr4_tiny_lu"]
 
 
 def rgrad_eps(g):
@@ -240,7 +241,7 @@ def test_reverse_path_gradients_match_reference(name):
     from hcflow_amd.config import param_spec
     g = load_golden(name)
     cfg, p = params_for(g)
-    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    q = trainable(p, cfg)
     fake = O.sr_inverse(t(g["lr"]), q, cfg, float(g["tau"]), eps=rgrad_eps(g))
     assert maxdiff(fake.detach(), g["fake"]) <= 1e-4
     loss = torch.nn.functional.l1_loss(fake, t(g["hr"]))
@@ -264,11 +265,12 @@ def rescale_step_loss(fwd, inv, hr, lr, eps):
     return l_lr, l_z, l_hr, fake_lr, fake_h
 
 
-def test_rescaling_step_gradients_match_reference():
+@pytest.mark.parametrize("name", ["grad_rescale_tiny", "grad_rescale_tiny_lu"])
+def test_rescaling_step_gradients_match_reference(name):
     from hcflow_amd.config import param_spec
-    g = load_golden("grad_rescale_tiny")
+    g = load_golden(name)
     cfg, p = params_for(g)
-    q = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in p.items()}
+    q = trainable(p, cfg)
     l_lr, l_z, l_hr, fake_lr, fake_h = rescale_step_loss(
         lambda x: O.rescale_forward(x, q, cfg), lambda x, e: O.rescale_inverse(x, q, cfg, 1.0, eps=e),
         t(g["hr"]), t(g["lr"]), rgrad_eps(g))

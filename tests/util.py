@@ -31,6 +31,26 @@ def params_for(g):
     return preset(name), p
 
 
+def trainable(p, cfg):
+    """A copy of the parameter dict with requires_grad on everything the reference trains: the buffers of the LU-decomposed
+    invertible conv (p, sign_s: Permutations.py:51-52) stay constants."""
+    from hcflow_amd.config import param_spec
+    fixed = {k for k, _, kind in param_spec(cfg) if kind in ("lu_p", "lu_sign_s")}
+    return {k: (v.clone() if k in fixed else v.clone().requires_grad_(True)) for k, v in p.items()}
+
+
+def spec_grads(net, cfg):
+    """Gradients of a drop-in module in param_spec (= state_dict) order as numpy arrays; zeros for tensors without one
+    (frozen Haar filters, the LU buffers)."""
+    from hcflow_amd.config import param_spec
+    sd = dict(net.named_parameters())
+    out = []
+    for k, shape, _ in param_spec(cfg):
+        prm = sd.get(k)
+        out.append(np.zeros(tuple(shape), np.float32) if prm is None or prm.grad is None else prm.grad.detach().cpu().numpy())
+    return out
+
+
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
