@@ -456,15 +456,25 @@ class _EngineModule(nn.Module):
     def _slots_for_self(self):
         cached = self.__dict__.get("_slots")
         if cached is not None and cached[0] == id(self):
-            return cached[1]
-        slots = []
+            # a replaced sub-module (EMA swap, a flow block exchanged by assignment) must not leave the engine bound to the old
+            # module's tensors: every (parent, attribute, child) edge of the resolved paths is re-checked (~600 dict lookups)
+            for parent, name, child in cached[2]:
+                if parent._modules.get(name) is not child:
+                    break
+            else:
+                return cached[1]
+        slots, edges, seen = [], [], set()
         for key in self._spec_keys:
             obj = self
             path = key.split(".")
             for a in path[:-1]:
-                obj = getattr(obj, a)
+                nxt = getattr(obj, a)
+                if (id(obj), a) not in seen:
+                    seen.add((id(obj), a))
+                    edges.append((obj, a, nxt))
+                obj = nxt
             slots.append((obj, path[-1]))
-        object.__setattr__(self, "_slots", (id(self), slots))
+        object.__setattr__(self, "_slots", (id(self), slots, edges))
         return slots
 
     def _device(self):

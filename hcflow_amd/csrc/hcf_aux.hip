@@ -105,6 +105,10 @@ int hcf_aux_conv2d(const float* x, int32_t cs_in, int32_t cin, int32_t B, int32_
       a.zeros = reinterpret_cast<const float*>(wk) + 16;
       int r2 = HCF_ERR_UNSUPPORTED;
       if ((cin & 15) == 0 && cin >= 64 && (nb == 32 || nb == 64)) {      // the dense 3x3 layers take the Winograd form
+        // the kernels over-read ONE chunk behind the pack, which must be zero: the region is shared by the 64- and the 32-wide
+        // layouts of successive output-channel blocks (cout = 96, 160 ...), whose chunk sizes and hence "behind the pack" differ
+        const size_t chunk_b = (nb == 64) ? 65536 : 32768;
+        if (hipMemsetAsync(wk + p.o_wino + (size_t)(cin / 16) * chunk_b, 0, chunk_b, st) != hipSuccess) return HCF_ERR_HIP;
         if (launch_repack_wino(r.w, cin, nb, nb, wk + p.o_wino, st) == HCF_OK) r2 = launch_conv_wino(a, wk + p.o_wino, st);
       }
       if (r2 == HCF_ERR_UNSUPPORTED) {

@@ -762,6 +762,7 @@ struct hcf_engine {
     if (fat) { a.out2 = fat->out2; a.act_t2 = fat->act2; a.res1_pre = fat->pre ? 1 : 0; }
     a.wino_ntile = cv.wino_ntile;
     if (dry()) return;
+    if (probe_on) { probe_conv(cv, srcs, H, W); ++launch_seq; }      // probe launches sit before this conv: it is never chained across them
     if (prof) {
       if (prof_used == prof_events.size()) {
         ProfRec r;
@@ -786,7 +787,6 @@ struct hcf_engine {
       if (!prof_events[prof_used].chained) hipEventRecord(prof_events[prof_used].e0, st);
     }
     ++launch_seq;
-    if (probe_on) probe_conv(cv, srcs, H, W);
     int r = HCF_ERR_UNSUPPORTED;
     const bool w4f = fat && fat->w4f_frag && fuse2;    // Winograd conv1 + the 1x1 layer in its epilogue
     if (use_f16 && cv.wpack_wino && (!fuse2 || w4f) && !tail && !wino_stale && !(g_f16x3_ablation & 256)) {
@@ -1419,6 +1419,7 @@ struct hcf_engine {
     if (hipSetDevice(device) != hipSuccess) return fail(HCF_ERR_HIP, "hipSetDevice failed");
     rc = HCF_OK;
     st = stream;
+    prof_last_seq = ~0ull;      // conv profiling: a pass never chains its first conv to the last conv of the PREVIOUS pass (host time)
     use_f16 = (precision == PREC_F16X3) && !an_active;   // also during the sizing run: fusion decisions must not differ
     key.push_back((long long)flags);
     key.push_back(use_f16 ? 1 : 0);

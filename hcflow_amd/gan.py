@@ -1,8 +1,9 @@
 """The auxiliary nets of the HCFlow+ / HCFlow++ recipes on the MI355X conv kernels.
 
 ``HCFlow_SR_model.py:75-95`` builds, beside netG, a VGG19 feature extractor (``networks.define_F`` -> ``VGGFeatureExtractor``,
-``discriminator_vgg_arch.py:110-137``) for the perceptual loss and a ``Discriminator_VGG_160`` (``:68-107``) trained with
-``GANLoss`` (``loss.py:19-51``); ``optimize_parameters`` (``HCFlow_SR_model.py:219-285``) runs them forward and backward every
+``discriminator_vgg_arch.py:110-137``) for the perceptual loss and a ``Discriminator_VGG_160`` (``:68-107``) trained with the
+reference's own ``GANLoss`` (``loss.py:19-51``: stock PyTorch criteria, no kernel behind it -- it stays the reference's file and is
+not restated here); ``optimize_parameters`` (``HCFlow_SR_model.py:219-285``) runs them forward and backward every
 step on ``fake_H`` / ``real_H`` batches. The classes here keep the reference's constructor signatures, ``state_dict`` keys /
 shapes (the parameter holders ARE ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.Linear`` modules, so checkpoints of the reference
 load strictly, ``load_network(..., netD)``) and call surface, and run EVERY CONVOLUTION -- > 99 % of their FLOPs -- through the
@@ -82,10 +83,14 @@ class _ConvNHWC(torch.autograd.Function):
         if y.shape[3] != cout:
             y.zero_()
         need = lib.hcf_aux_conv2d_workspace(cin, cout, k, B, H, W)
-        wk = work.get((cin, cout, k, B, H, W))
-        if wk is None or wk.numel() < need:
+        # keyed by DEVICE and STREAM too: nn.DataParallel replicas share this dict (replicate() shallow-copies __dict__), one
+        # replica thread per device (HCFlow_SR_model.py:76,94 wrap netD / netF), and a workspace holds packs, the range flag and
+        # weight-gradient partials of the call in flight
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, cin, cout, k, B, H, W)
+        wk = work.get(key)
+        if wk is None or wk.numel() < need or wk.device != x.device:
             wk = torch.zeros(need, dtype=torch.uint8, device=x.device)          # [0, 256): range flag + zero page
-            work[(cin, cout, k, B, H, W)] = wk
+            work[key] = wk
         flag_owner.append(wk)
         with torch.cuda.device(x.device):
             rc = lib.hcf_aux_conv2d(x.data_ptr(), cs, cin, B, H, W, w.data_ptr(), None if bias is None else bias.contiguous().data_ptr(),
@@ -144,12 +149,23 @@ class _AuxNet(nn.Module):
     def _run(self, body, x):
         prec = _PREC[self._prec[0]]
         flags = []
+        # a speculative f16x3 pass in train() mode updates every BatchNorm's running statistics; if it is thrown away (range
+        # overflow: its activations were inf / NaN) the exact re-run must start from the statistics BEFORE it
+        bn_state = None
+        if prec == 1 and self.training:
+            bn_state = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+                        for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.track_running_stats and m.running_mean is not None]
         out = body(x, flags, prec)
         if prec == 1 and flags:
             hit = torch.stack([f[:4].view(torch.int32)[0] for f in {id(f): f for f in flags}.values()]).any()
             if bool(hit):                                     # an activation left the f16 range: redo the pass exactly
                 for f in flags:
                     f[:4].zero_()
+                for m, mean, var, cnt in (bn_state or []):
+                    with torch.no_grad():
+                        m.running_mean.copy_(mean)
+                        m.running_var.copy_(var)
+                        m.num_batches_tracked.copy_(cnt)
                 out = body(x, [], 0)
         return out
 
@@ -256,29 +272,3 @@ class VGGFeatureExtractor(_AuxNet):
 
     def forward(self, x):
         return self._run(self._body, x)
-
-
-class GANLoss(nn.Module):
-    """loss.GANLoss (loss.py:19-51): gan / ragan -> BCE with logits, lsgan -> MSE, wgan-gp -> +-mean."""
-
-    def __init__(self, gan_type, real_label_val=1.0, fake_label_val=0.0):
-        super().__init__()
-        self.gan_type = gan_type.lower()
-        self.real_label_val = real_label_val
-        self.fake_label_val = fake_label_val
-        if self.gan_type in ("gan", "ragan"):
-            self.loss = nn.BCEWithLogitsLoss()
-        elif self.gan_type == "lsgan":
-            self.loss = nn.MSELoss()
-        elif self.gan_type == "wgan-gp":
-            self.loss = lambda inp, target: -1 * inp.mean() if target else inp.mean()
-        else:
-            raise NotImplementedError("GAN type [{:s}] is not found".format(self.gan_type))
-
-    def get_target_label(self, input, target_is_real):
-        if self.gan_type == "wgan-gp":
-            return target_is_real
-        return torch.empty_like(input).fill_(self.real_label_val if target_is_real else self.fake_label_val)
-
-    def forward(self, input, target_is_real):
-        return self.loss(input, self.get_target_label(input, target_is_real))

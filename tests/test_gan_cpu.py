@@ -1,6 +1,6 @@
 """hcflow_amd/gan.py on the CPU side: the algebra that lets the discriminator's 4x4 stride-2 convs run on the 3x3 kernels, the
 state-dict table against the reference's Discriminator_VGG_160 (fixture generated from the reference,
-tests/golden/make_golden.py::gen_gan_fixture), GANLoss against the reference's values, loud failure without a GPU."""
+tests/golden/make_golden.py::gen_gan_fixture), loud failure without a GPU."""
 import numpy as np
 import pytest
 import torch
@@ -33,17 +33,6 @@ def test_discriminator_state_dict_table_and_seeded_init_equal_the_reference():
     assert [",".join(str(v) for v in t.shape) for t in sd.values()] == [str(s) for s in g["shapes"]]
     dig = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in sd.values()])
     assert np.allclose(dig, g["param_digest"], rtol=1e-9, atol=1e-12)      # same modules, same order -> same default init
-
-
-def test_ganloss_values_equal_the_reference():
-    g = load_golden("gan_discriminator")
-    x = torch.linspace(-2, 2, 7).view(7, 1)
-    for t in ("gan", "ragan", "lsgan", "wgan-gp"):
-        c = gan.GANLoss(t, 1.0, 0.0)
-        got = np.array([float(c(x, True)), float(c(x, False))])
-        assert np.allclose(got, g["ganloss_" + t], rtol=1e-6, atol=1e-7), t
-    with pytest.raises(NotImplementedError):
-        gan.GANLoss("hinge")
 
 
 def test_vgg_feature_extractor_layer_table():

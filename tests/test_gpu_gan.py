@@ -22,6 +22,12 @@ def _grad_digest(g, i):
     return float(np.sqrt((g * g).sum())), float(g.sum()), float((g * r).sum())
 
 
+def _bce_gan(pred, target_is_real):
+    """What the reference's own loss.GANLoss computes for gan / ragan (loss.py:26-27,44-51); the class itself is not part of this
+    package (loss.py stays the reference's file)."""
+    return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, 1.0 if target_is_real else 0.0))
+
+
 @pytest.mark.parametrize("precision", ["exact", "f16x3"])
 def test_discriminator_step_matches_the_reference(precision):
     g = load_golden("gan_discriminator")
@@ -30,7 +36,7 @@ def test_discriminator_step_matches_the_reference(precision):
     gi = torch.Generator().manual_seed(int(g["input_seed"]))
     real = torch.rand(2, 3, 160, 160, generator=gi).cuda()
     fake = torch.rand(2, 3, 160, 160, generator=gi).cuda()
-    cri = gan.GANLoss("gan", 1.0, 0.0)
+    cri = _bce_gan            # loss.GANLoss("gan", 1.0, 0.0) of the reference (loss.py:19-51) = BCE with logits on constant labels
     pred_real, pred_fake = net(real), net(fake)
     assert maxdiff(pred_real, g["pred_real"]) <= 2e-4 and maxdiff(pred_fake, g["pred_fake"]) <= 2e-4
     l_real, l_fake = cri(pred_real, True), cri(pred_fake, False)
@@ -158,7 +164,7 @@ def test_hcflow_plus_plus_step_runs_end_to_end_on_the_engine_and_the_aux_nets():
     torch.manual_seed(3)
     netD = gan.Discriminator_VGG_160(3, 64).cuda().train()
     netF = gan.VGGFeatureExtractor(feature_layer=34, use_bn=False, use_input_norm=True, device=torch.device("cuda")).cuda().eval()
-    cri_gan = gan.GANLoss("ragan", 1.0, 0.0).cuda()
+    cri_gan = _bce_gan        # the reference's GANLoss("ragan", 1.0, 0.0): the same criterion on relativistic logits
     optG = torch.optim.Adam([p for p in netG.parameters() if p.requires_grad], lr=1e-4)
     optD = torch.optim.Adam(netD.parameters(), lr=1e-4)
     g = torch.Generator().manual_seed(1)
@@ -191,3 +197,20 @@ def test_hcflow_plus_plus_step_runs_end_to_end_on_the_engine_and_the_aux_nets():
     assert not torch.equal(netG.flow.level0_condFlow.conv_first.weight.detach(), w0)
     assert not torch.equal(netD.conv0_0.weight.detach(), d0)
     assert bool(torch.isfinite(l_d)) and bool(torch.isfinite(l_fea)) and bool(torch.isfinite(l_gan))
+
+
+def test_f16x3_overflow_retry_leaves_batchnorm_statistics_of_one_exact_pass():
+    """A speculative f16x3 pass whose input leaves the f16 range is thrown away and redone exactly; its train()-mode BatchNorm
+    updates (on inf / NaN activations) must not survive: running statistics and num_batches_tracked equal those of ONE exact
+    pass (what gets saved and used in eval())."""
+    torch.manual_seed(3)
+    a = gan.Discriminator_VGG_160(3, 64).cuda().train().set_precision("f16x3")
+    b = copy.deepcopy(a).set_precision("exact")
+    x = torch.rand(2, 3, 160, 160, generator=torch.Generator().manual_seed(9)).cuda() * 3e5      # |x| > 65504: not splittable
+    with torch.no_grad():
+        ya, yb = a(x), b(x)
+    assert torch.isfinite(ya).all() and torch.equal(ya, yb)
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        if "running_" in k or "num_batches" in k:
+            assert torch.isfinite(u.float()).all() and torch.equal(u, v), k
+    assert int(a.bn0_1.num_batches_tracked) == 1
