@@ -19,12 +19,16 @@ The module runs with ITS DEFAULT range-check policy ("sync": every call reads th
 re-run an overflowed pass exactly; `precision.range_check` names the policy that was timed; --range-check lazy defers the check).
 
 The JSON line also carries
-  roofline      dominant kernel = the conv instantiation with the LARGEST TOTAL TIME in the timed region (named as rocprofv3
-                prints it; every other instantiation is listed in conv_kernels): MFMA bound; achieved = algorithmic conv
+  roofline      dominant kernel = the conv kernel TEMPLATE FAMILY (e.g. conv_wino4_kernel<0|1|2>: the same code with 0 / 1 / 2
+                residual inputs in its epilogue, listed by rocprofv3 as three rows) with the LARGEST TOTAL TIME in the timed
+                region (every other family is listed in conv_kernels): MFMA bound; achieved = algorithmic conv
                 FLOPs (2*9*Cin*Cout per output pixel) / kernel time measured with HIP events on the launch stream inside the
                 timed region; peak 2500/3 TFLOP/s (f16 dense MFMA, 3 MFMAs per product block) resp. 157.3 TFLOP/s (fp32
                 matrix) from MI355X_MICROARCH.md; traffic = HBM bytes per launch from a separate rocprofv3 --pmc run,
                 REPLAYED from profiles/ (marked as such) or null
+  other_configs BASELINE.json configs 1 / 3 / 4 / 5 on one GPU, a few steps each AFTER (outside) the headline's timed region: B = 1
+                latency (what an unmodified test_HCFlow.py runs), Face x8 B = 32 tau sweep, the rescaling round trip on one
+                GPU's shard, the NLL training step -- value, unit, ms_per_step, mfma_frac each (N = 1 only; --no-other-configs)
   cpu_baseline  the CPU oracle (oracle/hcflow_oracle.py, a PyTorch-CPU port of the reference path) on this host:
                 BASELINE config 1 (B=1, tau=0, same LR size), median of >= 5 timed passes, rank 0, N = 1 only; its output is
                 kept and compared with the engine's on the same LR (precision.check.max_abs_diff_vs_cpu_path).
@@ -65,6 +69,10 @@ VARIANTS = {
               ("hcf::conv_mfma_kernel<1,2,true> 1x1", 1, 2, -1, ["exact<1,2>"]), ("hcf::conv_mfma_kernel<1,1,true> 1x1", 1, 1, -1, ["exact<1,1>"])],
 }
 IDEAL_GB_PER_IMAGE = 23.02            # layer-wise-ideal fp32 HBM traffic per image
+# BASELINE.md section 2, GFLOP per unit of the other BASELINE.json configurations (for other_configs[*].mfma_frac)
+GFLOP_FACE_X8_IMAGE = 146.64          # Face-SR x8 inverse, one 160x160 HR image (LR 20x20)
+GFLOP_RESCALE_ROUNDTRIP = 1087.69     # rescaling x4 forward + inverse, one 640x640 image
+GFLOP_TRAIN_SAMPLE = 184.27 * 3.0     # SR x4 NLL step, one 160x160 HR sample: forward x ~3 with the backward pass
 
 
 def main():
@@ -84,6 +92,9 @@ def main():
     ap.add_argument("--no-other-precision", action="store_true", help="skip the timed run of the other precision")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the f16x3-vs-exact deviation check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timed runs of BASELINE.json configs 1 / 3 / 4 / 5 after the headline (N = 1 only)")
+    ap.add_argument("--other-steps", type=int, default=8, help="timed steps per other configuration")
     ap.add_argument("--cpu-passes", type=int, default=5)
     args = ap.parse_args()
 
@@ -284,9 +295,123 @@ def main():
                           "check": check},
             "roofline": roof, "other_precision": other, "cpu_baseline": cpu,
         }
+        if world == 1 and not args.no_other_configs and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
+            del net, lr, out_all, hr_in
+            torch.cuda.empty_cache()
+            line["other_configs"] = other_configs(dev, params, args.other_steps, default_mode)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(dev, params_sr4, steps, mode):
+    """BASELINE.json configs 1 / 3 / 4 / 5 on ONE GPU, outside the headline's timed region, a few steps each (module defaults:
+    `mode` conv numerics, `sync` range-check policy), so that the driver's record carries them beside config 2:
+      config1_single_patch_latency   SR x4, B = 1, LR 160x160, tau 0 -- what an unmodified test_HCFlow.py runs (its loader is
+                                     batch 1, data/__init__.py:24): ms per call
+      config3_face_x8_tau_sweep      SR x8 (CelebA yml), B = 32, LR 20x20, tau cycling through 0.0 .. 0.9: HR images/s
+      config4_rescaling_roundtrip    rescaling x4 forward -> Quant -> inverse on one GPU's shard (8 of the 64 images of 640x640):
+                                     round trips/s
+      config5_nll_train_step         SR x4 NLL step as HCFlow_SR_model.optimize_parameters runs it (forward, backward, gradient
+                                     clipping, Adam), B = 16 HR 160x160 patches per GPU (global batch 128 on 8 GPUs): samples/s
+    mfma_frac = algorithmic FLOP/s / (2500 / 3 TFLOP/s: f16 dense MFMA peak, 3 MFMAs per product block),
+    the yardstick of the headline's roofline block (exact mode: 157.3)."""
+    import time
+    import torch
+    from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling, preset, make_params
+    peak = PEAK_F32_MFMA_TFLOPS if mode == "exact" else PEAK_F16_MFMA_TFLOPS / 3
+    sync = torch.cuda.synchronize
+
+    def build(name, p=None, train=False):
+        cfg = preset(name)
+        with contextlib.redirect_stdout(sys.stderr):
+            net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(p if p is not None else make_params(cfg, 1234), strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to(dev)
+        net = net.train() if train else net.eval()
+        return cfg, net.set_precision(mode)
+
+    def timed(fn, warmup=3):
+        for i in range(warmup):
+            fn(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        sync()
+        return (time.perf_counter() - t0) / steps
+
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        # ---- config 1
+        cfg, net = build("SR_DF2K_4X", params_sr4)
+        lr = torch.rand(1, 3, 160, 160, generator=g).to(dev)
+        dt = timed(lambda i: net(lr=lr, z=None, u=None, eps_std=0.0, reverse=True), warmup=5)
+        out["config1_single_patch_latency"] = {
+            "value": round(1e3 * dt, 3), "unit": "ms per call (B=1, LR 160x160 -> 640x640, tau 0)", "higher_is_better": False,
+            "ms_per_step": round(1e3 * dt, 3), "images_per_s": round(1.0 / dt, 2),
+            "mfma_frac": round(GFLOP_PER_IMAGE / 1e3 / dt / peak, 4)}
+        del net
+        # ---- config 3
+        cfg, net = build("SR_CelebA_8X")
+        lr = torch.rand(32, 3, 20, 20, generator=g).to(dev)
+        taus = [0.0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]
+        dt = timed(lambda i: net(lr=lr, z=None, u=None, eps_std=taus[i % len(taus)], reverse=True, seed=100 + i))
+        out["config3_face_x8_tau_sweep"] = {
+            "value": round(32 / dt, 2), "unit": "HR images/s (B=32, LR 20x20 -> 160x160, tau sweep 0.0..0.9)",
+            "higher_is_better": True, "ms_per_step": round(1e3 * dt, 3),
+            "mfma_frac": round(32 * GFLOP_FACE_X8_IMAGE / 1e3 / dt / peak, 4)}
+        del net
+        # ---- config 4
+        cfg, net = build("Rescaling_DF2K_4X")
+        hr = torch.rand(8, 3, 640, 640, generator=g).to(dev)
+
+        def roundtrip(i):
+            lr_hat, _, _ = net(hr=hr, reverse=False)
+            lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.
+            return net(lr=lrq, z=None, u=None, eps_std=1.0, reverse=True, seed=200 + i)
+        dt = timed(roundtrip)
+        out["config4_rescaling_roundtrip"] = {
+            "value": round(8 / dt, 2), "unit": "round trips/s per GPU (shard of 8 images 640x640; 64 over 8 GPUs)",
+            "higher_is_better": True, "ms_per_step": round(1e3 * dt, 3),
+            "mfma_frac": round(8 * GFLOP_RESCALE_ROUNDTRIP / 1e3 / dt / peak, 4)}
+        del net, hr
+    # ---- config 5 (autograd on)
+    cfg, net = build("SR_DF2K_4X", params_sr4, train=True)
+    hr = torch.rand(16, 3, 160, 160, generator=g).to(dev)
+    lr = torch.nn.functional.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    opt = torch.optim.Adam([q for q in net.parameters() if q.requires_grad], lr=2.5e-4, betas=(0.9, 0.99))
+    phases = [0.0, 0.0, 0.0]
+
+    def train_step(i):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        _, nll = net(hr=hr, lr=lr, reverse=False)
+        sync(); t1 = time.perf_counter()
+        nll.backward()
+        sync(); t2 = time.perf_counter()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 100.0)
+        opt.step()
+        sync(); t3 = time.perf_counter()
+        if i >= 2:
+            phases[0] += t1 - t0; phases[1] += t2 - t1; phases[2] += t3 - t2
+    tsteps = max(3, steps // 2)
+    for i in range(2 + tsteps):
+        train_step(i)
+    dt = sum(phases) / tsteps
+    out["config5_nll_train_step"] = {
+        "value": round(16 / dt, 2), "unit": "samples/s per GPU (B=16 HR 160x160; global batch 128 on 8 GPUs)",
+        "higher_is_better": True, "ms_per_step": round(1e3 * dt, 3),
+        "phases_ms": {"forward_incl_refresh": round(1e3 * phases[0] / tsteps, 2), "backward": round(1e3 * phases[1] / tsteps, 2),
+                      "clip_adam": round(1e3 * phases[2] / tsteps, 2)},
+        "mfma_frac": round(16 * GFLOP_TRAIN_SAMPLE / 1e3 / dt / peak, 4)}
+    out["note"] = ("timed after the headline, outside its timed region, %d steps each (train step: %d) on one GPU with the module's "
+                   "default policies; precision mode %s; mfma_frac against %.1f TFLOP/s" % (steps, tsteps, mode, peak))
+    return out
 
 
 def cpu_baseline(cfg, params, h, passes):

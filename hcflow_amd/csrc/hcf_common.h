@@ -187,6 +187,8 @@ struct EpiBwdArgs {
   float* sum_zy;           // nullable
   float zy_mult;
   float* absmax;           // nullable: max |gpre| as float bits (atomicMax on the int view; zero-initialised)
+  float* absmax2;          // nullable: a second slot raised the same way (shared by the convs of one dense block: the running
+                           // max over the gradients a gather-form data-gradient conv reads, hcf_engine_train.inc)
   float* part;             // per-block partial sums [conv_epilogue_bwd_blocks()][2][gy.n] (sum_pre, sum_zy): reduced in a fixed
                            // order by launch_sum_jobs, so parameter gradients are bit-reproducible; nullptr: fp32 atomics into sum_*
 };

@@ -54,6 +54,7 @@ struct Conv {
   float l_mult = 0.f;                                           // d logs = l_mult * sum(dz * y): ActNorm 1, Conv2dZeros 3
   struct TPack { float *wpack = nullptr, *wpack16 = nullptr; int nchunk = 0, npad = 0, src = 0, c0 = 0, n = 0; };
   std::vector<TPack> tpacks;                                    // data-gradient packs: (source window, <= 64-ch block)
+  bool gathered = false;                                        // a dense-block conv whose data gradients run in gather form (Rdb::gt)
 };
 
 struct Step {
@@ -89,7 +90,10 @@ struct Step {
 // fat = the "fat launch" form of conv3 / conv4 (profiles/r03_notes.md): c34 = conv3 + the [x, x1, x2] part of conv4 as ONE
 // 64-output-channel Winograd launch (second tile stored raw), c4b = conv4's completion over x3 (adds the stored partial)
 // Pair j = 0: (conv1, conv2), j = 1: (conv3, conv4): ca[j] = conv 2j+1 + the old-input part of conv 2j+2, cb[j] = the completion.
-struct Rdb { Conv c[5]; Conv ca[2], cb[2]; bool fat[2] = {false, false}; };
+// gt[m] (training): GATHER-form data-gradient pack of the block's tensor x_m (m = 0: the block input, m >= 1: growth tensor m):
+// dL/dx_m = conv3x3 over cat(dL/dpre of conv m+1 .. conv 4 (gc channels each), dL/dpre of conv 5 (nf)) with the transposed,
+// tap-flipped slices of those convs' weights -- one launch with K = (4 - m) gc + nf instead of one short-K launch per (conv, window).
+struct Rdb { Conv c[5]; Conv ca[2], cb[2]; bool fat[2] = {false, false}; Conv::TPack gt[5]; bool gather = false; };
 struct Rrdb { Rdb r[3]; };
 
 struct CondFlow {

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     __syncthreads();
     if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
     __syncthreads();
-    if (threadIdx.x == 0 && shm) atomicMax(reinterpret_cast<int*>(a.absmax), shm);
+    if (threadIdx.x == 0 && shm) {
+      atomicMax(reinterpret_cast<int*>(a.absmax), shm);
+      if (a.absmax2) atomicMax(reinterpret_cast<int*>(a.absmax2), shm);
+    }
   }
   if (a.sum_pre || a.sum_zy) {
     sh[0][threadIdx.x] = s_pre;

@@ -21,7 +21,9 @@ def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.rsplit(".", 1)[-1]
     if (mod in DUAL_PRECISION_MODULES and metafunc.definition.get_closest_marker("gpu") is not None
             and "precision" not in metafunc.fixturenames):
-        metafunc.parametrize("hcf_default_precision", _PRECISIONS, indirect=True)
+        only = metafunc.definition.get_closest_marker("precisions")     # e.g. semantics only the exact fp32-MFMA kernels define
+        modes = [p for p in _PRECISIONS if only is None or p in only.args] or list(only.args)
+        metafunc.parametrize("hcf_default_precision", modes, indirect=True)
 
 
 @pytest.fixture(autouse=True)
@@ -45,6 +47,7 @@ def hcf_default_precision(request, monkeypatch):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "precisions(*modes): restrict the session-level conv-precision parametrisation of this test")
 
 
 @pytest.fixture(scope="session")

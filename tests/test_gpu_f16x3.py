@@ -103,7 +103,7 @@ def test_f16x3_vs_exact_full_size_and_fallback():
     overflows f16 to exercise the automatic exact re-run."""
     cfg = preset("SR_4X_tiny")
     p = cached_params("SR_4X_tiny", 11)
-    net = build_net(cfg, p)
+    net = build_net(cfg, p).set_precision("exact")
     g = torch.Generator().manual_seed(8)
     lr = torch.rand(1, 3, 160, 160, generator=g).cuda()
     eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, 1, 160, 160)]
@@ -135,7 +135,7 @@ def test_large_grid_f16x3_matches_exact_and_is_deterministic(name, seed, B, size
     through every small-size test: it only showed with >= 2 co-resident blocks)."""
     cfg = preset(name)
     p = cached_params(name, seed)
-    net = build_net(cfg, p)
+    net = build_net(cfg, p).set_precision("exact")
     g = torch.Generator().manual_seed(21)
     lr = torch.rand(B, 3, size, size, generator=g).cuda()
     eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, size, size)]
@@ -157,7 +157,7 @@ def test_large_grid_forward_nll_f16x3_is_deterministic():
     """Same for the forward (encode + NLL) pass at B = 4, HR 320x320."""
     cfg = preset("SR_4X_tiny")
     p = cached_params("SR_4X_tiny", 11)
-    net = build_net(cfg, p)
+    net = build_net(cfg, p).set_precision("exact")
     g = torch.Generator().manual_seed(22)
     hr = torch.rand(4, 3, 320, 320, generator=g).cuda()
     lr = F.interpolate(hr, scale_factor=0.25, mode="bilinear", align_corners=False).clamp(0, 1)
@@ -185,7 +185,7 @@ def test_huge_image_takes_the_per_launch_fallbacks():
     the 1x1 epilogue) must step aside beforehand, the plain Winograd launches fall back to the direct kernels one by one, and the
     pass still agrees with the exact kernels."""
     cfg = preset("SR_4X_tiny")
-    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11)).set_precision("exact")
     g = torch.Generator().manual_seed(23)
     h, w = 1024, 1040
     lr = torch.rand(1, 3, h, w, generator=g).cuda()

@@ -17,9 +17,11 @@ _cache = {}
 
 def build_net(cfg, p):
     from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling
+    import os
     key = id(p)
+    mode = os.environ.get("HCFLOW_PRECISION", "f16x3")      # the session-level parametrisation (conftest.py) or the shipped default
     if key in _cache:
-        return _cache[key]
+        return _cache[key].set_precision(mode)              # a cached net may come from the other precision's run
     net = (HCFlowNet_SR if cfg.sr else HCFlowNet_Rescaling)(opt=cfg.to_opt(), step=0)
     net.load_state_dict(p, strict=True)
     for m in net.modules():

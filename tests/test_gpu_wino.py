@@ -90,7 +90,7 @@ def test_engine_uses_winograd_for_the_deep_dense_block_convs():
     from tests.util import cached_params, maxdiff
     from tests.test_gpu_nets import build_net
     cfg = preset("SR_4X_tiny")
-    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11)).set_precision("exact")      # the comparisons below start from the exact kernels
     g = torch.Generator().manual_seed(5)
     B, size = 2, 40
     lr = torch.rand(B, 3, size, size, generator=g).cuda()
@@ -126,7 +126,7 @@ def test_engine_runs_conditional_fcn_conv1_conv2_on_the_winograd_kernel():
     from tests.util import cached_params, maxdiff
     from tests.test_gpu_nets import build_net
     cfg = preset("SR_4X_tiny")
-    net = build_net(cfg, cached_params("SR_4X_tiny", 11))
+    net = build_net(cfg, cached_params("SR_4X_tiny", 11)).set_precision("exact")      # the comparisons below start from the exact kernels
     g = torch.Generator().manual_seed(6)
     B, h, w = 2, 37, 50                       # ragged against the 8 x 32 units
     lr = torch.rand(B, 3, h, w, generator=g).cuda()
@@ -164,7 +164,7 @@ def test_engine_runs_denseblock_coupling_convs_on_the_winograd_kernels():
     from tests.util import cached_params, maxdiff
     from tests.test_gpu_nets import build_net
     cfg = preset("Rescaling_4X_tiny")
-    net = build_net(cfg, cached_params("Rescaling_4X_tiny", 13))
+    net = build_net(cfg, cached_params("Rescaling_4X_tiny", 13)).set_precision("exact")
     g = torch.Generator().manual_seed(8)
     hr = torch.rand(2, 3, 136, 200, generator=g).cuda()                 # ragged against the 16 x 32 units at both levels
     n_dense = sum(cfg.K[:cfg.L]) - sum(cfg.after)                       # DenseBlock steps per pass
