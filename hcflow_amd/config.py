@@ -187,7 +187,25 @@ class NetConfig:
 
 # ---------------------------------------------------------------------------- presets
 def preset(name: str) -> NetConfig:
-    """Configs shipped by the reference (codes/options/test/*.yml network_G blocks)."""
+    """Configs shipped by the reference (codes/options/test/*.yml network_G blocks). ``base@K=1,3,2;after=0,2;nb=0,2`` names a
+    depth variant of ``base`` (flow steps per level, how many of them act on the split half, RRDB counts of the two trunks):
+    the option space FlowNet.__init__ accepts beyond the shipped ymls (reference-generated fixtures: tests/golden/net_var_*)."""
+    if "@" in name:
+        base, mods = name.split("@", 1)
+        c = preset(base)
+        for kv in mods.split(";"):
+            k, v = kv.split("=")
+            vals = [int(x) for x in v.split(",")]
+            if k == "K":
+                c.K = vals
+            elif k == "after":
+                c.after = vals
+            elif k == "nb":
+                c.rrdb_nb = (vals[0], vals[1])
+            else:
+                raise KeyError(kv)
+        c.validate()
+        return c
     if name == "SR_DF2K_4X":        # test_SR_DF2K_4X_HCFlow.yml:52-76
         return NetConfig(kind="SR", scale=4, quant=64.0, L=2, K=[26, 26, 26], after=[13, 13],
                          rrdb_nb=(7, 7))

@@ -736,6 +736,20 @@ def main():
                              img_tensor(im["butterfly_hr"]), seed=75, taus=(0.0, 1.0), images="butterfly")
         if only == "real":
             return
+    if only in ("all", "var"):
+        # depth / split / trunk variants of every net family (the option space the fuzz tests draw from, tests/test_gpu_fuzz.py):
+        # the oracle shares hcflow_amd.config.layer_plan with the product, so each family also gets fixtures from the REFERENCE's
+        # own FlowNet constructors -- incl. the corner cases K = 1, after = 0, after = K, an empty first trunk
+        gen_net_fixture("net_var_sr4_a", "SR_4X_tiny@K=1,3,2;after=0,3;nb=0,1", ref_sr, ref_rs, B=2, h=6, w=10, seed=101)
+        gen_net_fixture("net_var_sr4_b", "SR_4X_tiny@K=3,2,2;after=3,1;nb=2,2", ref_sr, ref_rs, B=2, h=8, w=6, seed=102)
+        gen_net_fixture("net_var_sr8_a", "SR_8X_tiny@K=2,1,3,2;after=1,0,3;nb=0,2", ref_sr, ref_rs, B=2, h=4, w=6, seed=103)
+        gen_net_fixture("net_var_sr8_b", "SR_8X_tiny@K=1,4,2,2;after=1,2,0;nb=1,1", ref_sr, ref_rs, B=2, h=6, w=4, seed=104)
+        gen_net_fixture("net_var_rescale_a", "Rescaling_4X_tiny@K=2,4,2;after=0,4;nb=0,1", ref_sr, ref_rs, B=2, h=6, w=10, seed=105,
+                        taus=(0.0, 1.0))
+        gen_net_fixture("net_var_rescale_b", "Rescaling_4X_tiny@K=3,1,2;after=2,0;nb=2,2", ref_sr, ref_rs, B=2, h=8, w=6, seed=106,
+                        taus=(0.0, 1.0))
+        if only == "var":
+            return
     if only in ("all", "lu"):
         # LU-decomposed invertible 1x1 convs (Permutations.py:41-57,78-92) in every flow step: inverse / NLL / rescaling fixtures,
         # the NLL-step gradients of l / log_s / u, and the reverse-path gradients

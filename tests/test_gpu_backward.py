@@ -500,7 +500,7 @@ def test_dense_block_gather_form_data_gradients_equal_the_per_conv_form(precisio
             if "ActNorm" in type(m).__name__:
                 m.inited = True
         net = net.to("cuda:0").train().set_precision(precision)
-        opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=1e-3)
+        opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=1e-7)      # gradients reach 1e4 on these random weights
         steps = []
         for it in range(2):
             opt.zero_grad(set_to_none=True)

@@ -10,8 +10,11 @@ from tests.util import load_golden, params_for, t, maxdiff, cached_params
 
 pytestmark = pytest.mark.gpu
 
-NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full"]
-NETS_RS = ["net_rescale_tiny", "net_rescale_full"]
+# net_var_*: reference-generated fixtures for depth / split / trunk variants (the option space of tests/test_gpu_fuzz.py, whose
+# oracle shares layer_plan with the product: these do not)
+NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full", "net_var_sr4_a", "net_var_sr4_b", "net_var_sr8_a",
+           "net_var_sr8_b"]
+NETS_RS = ["net_rescale_tiny", "net_rescale_full", "net_var_rescale_a", "net_var_rescale_b"]
 _cache = {}
 
 
@@ -281,6 +284,7 @@ def test_config3_face_x8_tau_sweep():
         assert torch.equal(a, b)
         for tau in (0.2, 0.6, 1.0):
             eps = [u * tau for u in unit]
+            net.set_precision("exact")
             ex = net.reverse_flow_diracLR(lr, None, None, eps_std=tau, eps=eps, clamp=False)
             net.set_precision("f16x3")
             try:
@@ -321,6 +325,7 @@ def test_full_size_div2k_validation_image_ragged_shape():
     lr = torch.rand(1, 3, 339, 510, generator=g).cuda()
     eps = [torch.randn(s, generator=g).cuda() * 0.9 for s in eps_shapes(cfg, 1, 339, 510)]
     with torch.no_grad():
+        net.set_precision("exact")
         ex = net.reverse_flow_diracLR(lr, None, None, eps_std=0.9, eps=eps, clamp=False)
         assert tuple(ex.shape) == (1, 3, 1356, 2040) and bool(torch.isfinite(ex).all())
         net.set_precision("f16x3")

@@ -79,8 +79,10 @@ def test_rescaling_ops():
 
 
 # *_lu: every invertible 1x1 conv LU-decomposed (Permutations.py:41-57,78-92; make_golden.py ReferenceLU)
-NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full", "net_sr4_tiny_lu", "net_sr8_tiny_lu"]
-NETS_RS = ["net_rescale_tiny", "net_rescale_full", "net_rescale_tiny_lu"]
+# net_var_*: depth / split / trunk variants (K per level, after_flowstep, RRDB counts) built by the reference's own constructors
+NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full", "net_sr4_tiny_lu", "net_sr8_tiny_lu",
+           "net_var_sr4_a", "net_var_sr4_b", "net_var_sr8_a", "net_var_sr8_b"]
+NETS_RS = ["net_rescale_tiny", "net_rescale_full", "net_rescale_tiny_lu", "net_var_rescale_a", "net_var_rescale_b"]
 
 
 def _eps(g, pre):
