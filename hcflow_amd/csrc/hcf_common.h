@@ -117,7 +117,12 @@ struct WgradArgs {
   int dbg;                 // timing ablations (HCF_WG_DBG): 1 no MFMAs, 2 no epilogue, 4 no global loads
 };
 size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);
-int launch_conv_wgrad(const WgradArgs& a, hipStream_t st);
+// The fixed-order reduction of a launch's partial tiles as a JOB: launch_conv_wgrad(a, st, &job) leaves the partial tiles in a.part
+// and returns the reduce step instead of launching it; launch_wgrad_reduce_batch runs any number of them as ONE launch (the training
+// step: ~630 reduce launches of ~7 us become ~40). Same summation order per dW element as the stand-alone reduce.
+struct WgradReduceJob { WgradArgs a; int nx, nicb, nocb, nbx; long long blk0; };
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t st, WgradReduceJob* defer = nullptr);
+int launch_wgrad_reduce_batch(const WgradReduceJob* jobs_dev, int njobs, long long nblocks, hipStream_t st);
 int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |g| (out zero-initialised)
 int launch_wino_vmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |B^T d B| over the F(2x2,3x3) patches
 
@@ -255,6 +260,9 @@ int launch_quant_logp_bwd(View z, const float* lr_nchw, View gz, int B, int H, i
 int launch_add_view(View in, View out, int B, int H, int W, float alpha, hipStream_t st);      // out += alpha * in
 int launch_add_const(float* p, size_t n, float v, hipStream_t st);                             // p[i] += v
 int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st);              // y += alpha * x
+// many of the two above in one launch (the data-independent log-det terms of a training step: 2 small updates per flow step)
+struct AxpyJob { const float* x; float* y; int n; float alpha; };                              // y += alpha * (x ? x : 1)
+int launch_axpy_jobs(const AxpyJob* jobs_dev, int njobs, hipStream_t st);
 // LU-decomposed invertible 1x1 conv (Permutations.py:78-86: W = P L U', L = l o mask + I, U' = u o mask^T + diag(sign_s e^log_s)):
 // chain rule of dL/dW into the factors, A = P^T dW:  dl += strict_lower(A U'^T),  du += strict_upper(L^T A),
 // dlog_s[i] += (L^T A)[i][i] * U'[i][i].  All matrices [C][C] row-major, C <= 48; one block.

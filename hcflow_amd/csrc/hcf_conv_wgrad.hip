@@ -424,9 +424,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
 }
 
 // dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nx, int taps) {
-  const int icb = blockIdx.y, ocb = blockIdx.z;
-  const int e = blockIdx.x * 256 + threadIdx.x;          // (tap, m, n)
+// (bx, icb, ocb) = this block's coordinates in a grid of (ceil(taps * 1024 / 256), nicb, nocb)
+__device__ __forceinline__ void wgrad_reduce_block(const WgradArgs& a, int nx, int taps, int bx, int icb, int ocb, int nicb, int nocb) {
+  const int e = bx * 256 + threadIdx.x;          // (tap, m, n)
   if (e >= taps * 1024) return;
   const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
   // locate the channel block
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
   }
   const int ic = blk * 32 + m, oc = ocb * 32 + n;
   if (ic >= a.src[si].n || oc >= a.g.n) return;
-  const size_t stride = (size_t)gridDim.y * gridDim.z * taps * 1024;
-  const float* p = a.part + ((size_t)icb * gridDim.z + ocb) * (taps * 1024) + e;
+  const size_t stride = (size_t)nicb * nocb * taps * 1024;
+  const float* p = a.part + ((size_t)icb * nocb + ocb) * (taps * 1024) + e;
   // fixed summation order (8 interleaved partial sums, then their sum): deterministic, and 8 loads in flight
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int b = 0;
@@ -450,6 +450,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
   for (; b < nx; ++b) s8[b & 7] += p[(size_t)b * stride];
   const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   a.dw[((size_t)oc * a.cin_total + ic_base + ic) * taps + t] += a.negate ? -s : s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nx, int taps) {
+  wgrad_reduce_block(a, nx, taps, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gridDim.z);
+}
+
+// many reduce steps in one launch: block -> job by binary search over the jobs' first-block numbers (blk0, ascending)
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceJob* __restrict__ jobs, int njobs) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = njobs;                       // invariant: jobs[lo].blk0 <= blk < (hi < njobs ? jobs[hi].blk0 : total)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid;
+  }
+  const WgradReduceJob& j = jobs[lo];
+  int r = (int)(blk - j.blk0);
+  const int ocb = r % j.nocb; r /= j.nocb;
+  const int icb = r % j.nicb; r /= j.nicb;
+  wgrad_reduce_block(j.a, j.nx, j.a.taps, r, icb, ocb, j.nicb, j.nocb);
 }
 
 // max |g| over a channel window (float bits ordered like ints for non-negative values); *out zero-initialised by the caller
@@ -542,7 +561,13 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   return (size_t)nblk_x * pairs * a0.taps * 1024;
 }
 
-int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
+int launch_wgrad_reduce_batch(const WgradReduceJob* jobs_dev, int njobs, long long nblocks, hipStream_t st) {
+  if (!jobs_dev || njobs < 1 || nblocks < 1 || nblocks > 0x7fffffffLL) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(wgrad::wgrad_reduce_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer) {
   if (a0.nsrc < 1 || a0.nsrc > kMaxSrc || (a0.taps != 9 && a0.taps != 1) || !a0.dw || !a0.g.p || a0.g.n < 1 || !a0.part)
     return HCF_ERR_ARG;
   WgradArgs a = a0;
@@ -588,6 +613,10 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st) {
   else if (a.taps == 9) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, false>), grid, dim3(256), 0, st, a);
   else if (vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<1, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<1, false>), grid, dim3(256), 0, st, a);
+  if (defer) {                                    // the caller batches the reduce steps (launch_wgrad_reduce_batch)
+    defer->a = a; defer->nx = nblk_x; defer->nicb = nicb; defer->nocb = nocb; defer->nbx = (a.taps * 1024 + 255) / 256; defer->blk0 = 0;
+    return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+  }
   const dim3 rgrid((unsigned)((a.taps * 1024 + 255) / 256), (unsigned)nicb, (unsigned)nocb);
   hipLaunchKernelGGL(wgrad::wgrad_reduce_kernel, rgrid, dim3(256), 0, st, a, nblk_x, a.taps);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;

@@ -1544,6 +1544,8 @@ void hcf_destroy(hcf_engine* e) {
   if (e->garena.base) hipFree(e->garena.base);
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
+  if (e->wg_jobs_dev) hipFree(e->wg_jobs_dev);
+  if (e->axpy_jobs_dev) hipFree(e->axpy_jobs_dev);
   if (e->sum_jobs_dev) hipFree(e->sum_jobs_dev);
   if (e->rt.blob) hipFree(e->rt.blob);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }

@@ -461,6 +461,16 @@ int launch_axpy(const float* x, float* y, size_t n, float alpha, hipStream_t st)
   HCF_RET_T();
 }
 
+__global__ __launch_bounds__(256) void axpy_jobs_kernel(const AxpyJob* jobs) {
+  const AxpyJob j = jobs[blockIdx.x];
+  for (int i = threadIdx.x; i < j.n; i += 256) j.y[i] += j.alpha * (j.x ? j.x[i] : 1.f);
+}
+int launch_axpy_jobs(const AxpyJob* jobs_dev, int njobs, hipStream_t st) {
+  if (njobs <= 0) return HCF_OK;
+  hipLaunchKernelGGL(axpy_jobs_kernel, dim3((unsigned)njobs), dim3(256), 0, st, jobs_dev);
+  HCF_RET_T();
+}
+
 // ---- LU-decomposed invertible 1x1 conv: dL/dW -> dl, du, dlog_s (see hcf_common.h) --------------------------------------
 __global__ __launch_bounds__(256) void lu_chain_kernel(const LuChainArgs a) {
   constexpr int MAXC = 48;
