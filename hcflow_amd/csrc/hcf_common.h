@@ -99,6 +99,8 @@ size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st);   // pack rebuilt from device weights
+struct RepackWinoJob { const float* w; void* pk; int cin, cout, cout_tile; long long blk0; };              // blk0: first block of the job (ascending)
+int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long nblocks, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------
 // dW[oc][ic][tap] += sum_pixels X[pixel + tap][ic] * G[pixel][oc]   (PyTorch weight layout, fp32 atomics)

@@ -39,9 +39,8 @@ size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out) {
 
 // Device-side rebuild of a Winograd pack from the PyTorch-layout weight in device memory (after an optimiser step): the same
 // arithmetic as wino::pack_weights_wino, one thread per (output channel, input channel).
-__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk) {
+__device__ __forceinline__ void repack_wino_one(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk, int idx) {
 #pragma clang fp contract(off)
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= cin * cout) return;
   const int oc = idx / cin, ic = idx - oc * cin;
   const float* g = w + (size_t)idx * 9;
@@ -64,6 +63,26 @@ __global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restric
       pk[o] = __builtin_bit_cast(uint16_t, p0);
       pk[o + 512] = __builtin_bit_cast(uint16_t, p1);
     }
+}
+
+__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk) {
+  repack_wino_one(w, cin, cout, cout_tile, pk, blockIdx.x * 256 + threadIdx.x);
+}
+// every Winograd pack of the net in one launch (the training step's refresh: ~500 packs): block -> job by binary search over blk0
+__global__ __launch_bounds__(256) void repack_wino_batch_kernel(const RepackWinoJob* __restrict__ jobs, int njobs) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = njobs;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid;
+  }
+  const RepackWinoJob j = jobs[lo];
+  repack_wino_one(j.w, j.cin, j.cout, j.cout_tile, reinterpret_cast<uint16_t*>(j.pk), (int)(blk - j.blk0) * 256 + threadIdx.x);
+}
+int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long nblocks, hipStream_t st) {
+  if (!jobs_dev || njobs < 1 || nblocks < 1 || nblocks > 0x7fffffffLL) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(repack_wino_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
 // cout_tile = the pack's width (32 / 64; > cout for the zero-padded tiles, whose extra rows stay as the host pack left them)

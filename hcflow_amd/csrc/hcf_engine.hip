@@ -1548,6 +1548,7 @@ void hcf_destroy(hcf_engine* e) {
   if (e->axpy_jobs_dev) hipFree(e->axpy_jobs_dev);
   if (e->sum_jobs_dev) hipFree(e->sum_jobs_dev);
   if (e->rt.blob) hipFree(e->rt.blob);
+  if (e->rt.wino) hipFree(e->rt.wino);
   for (auto& pr : e->prof_events) { hipEventDestroy(pr.e0); hipEventDestroy(pr.e1); }
   delete e;
 }

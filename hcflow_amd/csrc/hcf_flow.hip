@@ -42,6 +42,77 @@ __global__ __launch_bounds__(256) void step_tail_inv_kernel(const StepArgs a) {
   if (a.zpad16) store_pad16<CMAX>(a.zpad16, pix, a.zpad_n, y);
 }
 
+// The same for the 25..48-channel steps (the x8 net's deepest level: 20 x 20 pixels per sample, a C x C mat-vec of up to 2 304
+// FMAs per pixel): one thread per pixel leaves 4/5 of the chip idle for 40 us per step at B = 32. Here a block takes 64 pixels and
+// its four waves a quarter of the channels each (wave-uniform: the matrix rows still come through scalar loads): coupling^-1 on
+// the wave's own channels -> LDS [channel][pixel] -> every wave reads the whole vector and computes its 12 output rows.
+__global__ __launch_bounds__(256) void step_tail_inv48_kernel(const StepArgs a) {
+  __shared__ float zs[48 * 64];
+  const int hw = a.H * a.W;
+  const int lane = threadIdx.x & 63;
+  const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const bool ok = i < hw;
+  const size_t pix = (size_t)blockIdx.y * hw + (ok ? i : hw - 1);
+  const int C = a.C, ns = a.ns, c0 = part * 12;
+  {
+    const float* zp = a.z.p + pix * a.z.cs + a.z.c0;
+    const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int c = c0 + k;
+      float v = 0.f;
+      if (c < C) {
+        v = zp[c];
+        if (a.mode == CPL_AFFINE) {
+          if (c >= ns) {
+            const int j = c - ns;
+            v = v * expf(-logscale_of(hp[2 * j + 1])) - hp[2 * j];       // z2 * exp(-logscale) - shift  (AffineCouplings.py:65-87)
+          }
+        } else if (c < 3) {
+          v = v - hp[c];                                                 // AffineCoupling3shift, LRvsothers = False (:150-153)
+        }
+      }
+      zs[c * 64 + lane] = v;
+    }
+  }
+  __syncthreads();
+  float z[48];
+#pragma unroll
+  for (int c = 0; c < 48; ++c) z[c] = zs[c * 64 + lane];
+  float y[12];
+  if (a.mat) {
+    const step_cptr M = const_table(a.mat) + c0 * 48;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 48; ++k) acc = fmaf(M[r * 48 + k], z[k], acc);
+      y[r] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 12; ++r) y[r] = zs[(c0 + r) * 64 + lane];
+  }
+  const step_cptr mul = const_table(a.an_mul) + c0, bias = const_table(a.an_bias) + c0;
+#pragma unroll
+  for (int r = 0; r < 12; ++r) y[r] = y[r] * mul[r] - bias[r];                                        // x * exp(-logs) - bias
+  if (!ok) return;
+  float* op = a.out.p + pix * a.out.cs + a.out.c0 + c0;
+  if (((a.out.cs | a.out.c0) & 3) == 0 && (C & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (c0 + 4 * q < C) {
+        step_f32x4 t = {y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+        *reinterpret_cast<step_f32x4*>(op + 4 * q) = t;
+      }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 12; ++r)
+      if (c0 + r < C) op[r] = y[r];
+  }
+}
+
 // ---- forward flow step head: actnorm -> W  (FlowStep.py:40-47) --------------------------------
 template <int CMAX>
 __global__ __launch_bounds__(256) void step_head_fwd_kernel(const StepArgs a) {
@@ -111,6 +182,11 @@ int step_cmax(int C) { return C <= 8 ? 8 : C <= 12 ? 12 : C <= 24 ? 24 : C <= 48
 
 int launch_step_tail_inv(const StepArgs& a, hipStream_t st) {
   if (a.C < 1 || a.H < 1 || a.W < 1 || a.B < 1) return HCF_ERR_ARG;
+  if (a.C > 24 && a.C <= 48 && !a.aux.p && !a.zpad16) {        // (inference; the taped passes keep the one-thread-per-pixel form)
+    const dim3 grid((unsigned)((a.H * a.W + 63) / 64), (unsigned)a.B);
+    hipLaunchKernelGGL(step_tail_inv48_kernel, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+  }
   HCF_DISPATCH_CMAX(step_tail_inv_kernel, a, st);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
