@@ -197,7 +197,7 @@ def main():
         traffic, tnote = None, ("not measured in this run (PMC counters need separate rocprofv3 --pmc passes: "
                                 "profiles/ holds them per round)")
         try:
-            tfile = next(f for f in ("r03_traffic_pmc.json", "r02_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tfile = next(f for f in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             ents = [tj["kernels"][k] for k in dom["_tkeys"] if k in tj["kernels"]]
             if ents and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:       # launch-weighted mean over the instantiation's keys
