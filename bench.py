@@ -298,7 +298,10 @@ def main():
         if world == 1 and not args.no_other_configs and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
             del net, lr, out_all, hr_in
             torch.cuda.empty_cache()
-            line["other_configs"] = other_configs(dev, params, args.other_steps, default_mode)
+            try:                                     # the headline line is printed whatever happens in the side measurements
+                line["other_configs"] = other_configs(dev, params, args.other_steps, default_mode)
+            except Exception as e:  # noqa: BLE001
+                line["other_configs"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
