@@ -290,3 +290,43 @@ def test_random_rescaling_configurations_f16x3_match_oracle(seed):
     assert float((z1g.cpu() - z1o).abs().max()) <= 1e-4 * max(1.0, float(z1o.abs().max()))
     assert float((z2g.cpu() - z2o).abs().max()) <= 1e-4 * max(1.0, float(z2o.abs().max()))
     assert float((inv_g.cpu() - inv_o).abs().max()) <= 1e-4 * max(1.0, float(inv_o.abs().max()))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_lu_configurations_match_oracle_incl_gradients(seed):
+    """LU-decomposed invertible convs (Permutations.py:41-57,78-92) in randomly configured SR nets: inverse, NLL and the NLL-step
+    gradients (l, log_s, u among them) against the oracle / its autograd, module default precision."""
+    from hcflow_amd import HCFlowNet_SR
+    from tests.util import trainable
+    rng = np.random.default_rng(8000 + seed)
+    base = preset("SR_4X_tiny_LU" if seed % 2 == 0 else "SR_8X_tiny_LU")
+    K = [int(rng.integers(1, 4)) for _ in range(len(base.K))]
+    after = [int(rng.integers(0, K[l] + 1)) for l in range(len(base.after))]
+    cfg = dataclasses.replace(base, K=K, after=after, rrdb_nb=(int(rng.integers(0, 2)), int(rng.integers(1, 3))))
+    cfg.validate()
+    assert cfg.lu
+    p = make_params(cfg, 1100 + seed)
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(p, strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").train()
+    g = torch.Generator().manual_seed(seed)
+    h, w = int(rng.integers(2, 5)) * 2, int(rng.integers(2, 6)) * 2
+    lr = torch.rand(2, 3, h, w, generator=g)
+    hr = torch.rand(2, 3, h * cfg.scale, w * cfg.scale, generator=g) * 0.6 + 0.2
+    noise = torch.rand(hr.shape, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.6 for s in eps_shapes(cfg, 2, h, w)]
+    with torch.no_grad():
+        want = O.sr_inverse(lr, p, cfg, 0.6, eps=eps, clamp=False)
+        got = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.6, eps=[e.cuda() for e in eps], clamp=False)
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    q = trainable(p, cfg)
+    nll_o = O.sr_forward(hr, lr, q, cfg, noise=noise)[1]
+    nll_o.backward()
+    net.zero_grad()
+    nll_g = net(hr=hr.cuda(), lr=lr.cuda(), reverse=False, noise=noise.cuda())[1]
+    assert abs(float(nll_g.detach()) - float(nll_o.detach())) <= 2e-4 * max(1.0, abs(float(nll_o.detach())) / 100)
+    nll_g.backward()
+    _grad_cmp(net, q, cfg, 5e-4)
