@@ -1545,6 +1545,9 @@ void hcf_destroy(hcf_engine* e) {
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
   if (e->wg_jobs_dev) hipFree(e->wg_jobs_dev);
+  if (e->wg_stream) { hipStreamSynchronize(e->wg_stream); hipStreamDestroy(e->wg_stream); }
+  if (e->wg_ev) hipEventDestroy(e->wg_ev);
+  if (e->wg_done) hipEventDestroy(e->wg_done);
   if (e->axpy_jobs_dev) hipFree(e->axpy_jobs_dev);
   if (e->sum_jobs_dev) hipFree(e->sum_jobs_dev);
   if (e->rt.blob) hipFree(e->rt.blob);

@@ -3,6 +3,8 @@
 // elementwise / per-pixel work; the GEMM-shaped parts of the backward pass are the data-gradient convs (forward
 // kernels on transposed weight packs) and hcf_conv_wgrad.hip.
 #include "hcf_common.h"
+#include <algorithm>
+#include <cstdlib>
 #include "hcf_step_math.h"
 
 namespace hcf {
@@ -160,10 +162,13 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_vec_kernel(const EpiBwd
   }
 }
 
-constexpr int kEpiBwdPixelsPerBlock = 96;    // >= 1000 blocks for a 16 x 80 x 80 tensor
+static int epi_bwd_ppb() {                   // pixels per block; 192: ~530 blocks for a 16 x 80 x 80 tensor (96 / 192 / 384 measured 84.3 / 82.6 / 86.8 ms per training step) (HCF_EPI_PPB: experiments)
+  static const int v = getenv("HCF_EPI_PPB") ? std::max(32, atoi(getenv("HCF_EPI_PPB"))) : 192;
+  return v;
+}
 int conv_epilogue_bwd_blocks(int B, int H, int W) {
   const long long npix = (long long)B * H * W;
-  return (int)((npix + kEpiBwdPixelsPerBlock - 1) / kEpiBwdPixelsPerBlock);
+  return (int)((npix + epi_bwd_ppb() - 1) / epi_bwd_ppb());
 }
 
 __global__ __launch_bounds__(256) void sum_jobs_kernel(const SumJob* jobs) {
@@ -188,7 +193,7 @@ int launch_sum_jobs(const SumJob* jobs_dev, int njobs, hipStream_t st) {
 int launch_conv_epilogue_bwd(const EpiBwdArgs& a, hipStream_t st) {
   if (a.gy.n < 1 || a.gy.n > 256 || a.gpre.n != a.gy.n) return HCF_ERR_ARG;
   const long long npix = (long long)a.B * a.H * a.W;
-  const int ppb = kEpiBwdPixelsPerBlock;
+  const int ppb = epi_bwd_ppb();
   auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
   const bool vec = (a.gy.n & 3) == 0 && a.gy.n >= 4 && v4(a.gy) && v4(a.gpre) && v4(a.y) && v4(a.g1) && v4(a.g2) &&
                    (!a.scale || (reinterpret_cast<uintptr_t>(a.scale) & 15) == 0);
