@@ -62,7 +62,10 @@ struct Args {
   // "fat" dense-block launches (hcf_engine.hip run_rdb): the 64-channel kernel may route its second 32-channel tile to another
   // tensor with its own activation (conv k's outputs + the old-input part of conv k+1 as ONE launch), and the 32-channel kernel
   // may add a stored partial sum BEFORE bias / activation (conv k+1's completion): pre != null -> res1 / res2 are unused.
-  float* out2; int out2_cs, out2_c0, act2;                  // 64-channel kernel only; null: both tiles go to `out`
+  float* out2; int out2_cs, out2_c0, act2;                  // 64-channel kernel: the second 32-channel tile goes here with activation act2
+                                                            // (null: both tiles go to `out`). 32-channel kernel (round 4, 16-channel dense
+                                                            // blocks): channels [out2_split, 32) of the tile go here, out2_split = 16
+  int out2_split;
   const float* pre; int pre_cs, pre_c0;                     // 32-channel kernel only
   // fused 1x1 second layer (FCN conv1 -> conv2 of the conditional coupling nets, Basic.py:441-447; hcf_engine.hip
   // run_coupling_net): 64-channel kernel only. The first layer's tile (after bias / scale / activation) is split and parked in
@@ -475,6 +478,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
       const int cb = ent * 32 + 8 * qd + 4 * hd;
       const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + cb * 4);
       const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB2_OFF + 256 + cb * 4);
+      // fat launch of a 16-channel dense block: the upper half of the tile is the NEXT conv's partial sum, stored raw elsewhere
+      const bool second = (RES == 0) && a.out2 != nullptr && cb >= a.out2_split;
+      const float slope_l = second ? (a.act2 == 1 ? 0.f : a.act2 == 2 ? 0.2f : 1.f) : slope;
       __builtin_amdgcn_s_barrier();                // every wave is done reading the stage
 #pragma unroll
       for (int oa = 0; oa < 2; ++oa) {
@@ -532,11 +538,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
               chk = fmaf(yv, 0.f, chk);
               float z = fmaf(yv, ms[e], bs[e]);
               if (RES == 3) z = fmaf(rv1[sgrp][ob][e], ms[e] * 2048.f, z);      // stored partial sum, scaled like the conv sum
-              v[e] = fmaxf(z, slope * z);           // none / relu / leaky relu for slope 1 / 0 / 0.2 (a non-finite z trips chk)
+              v[e] = fmaxf(z, slope_l * z);         // none / relu / leaky relu for slope 1 / 0 / 0.2 (a non-finite z trips chk)
               if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[sgrp][ob][e]);
               if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[sgrp][ob][e]);
             }
-            if (oks[sgrp][ob] && cb < a.cout) *reinterpret_cast<f32x4*>(a.out + pixs[sgrp][ob] * a.out_cs + a.out_c0 + cb) = v;
+            if (oks[sgrp][ob] && cb < a.cout) {
+              if (second) *reinterpret_cast<f32x4*>(a.out2 + pixs[sgrp][ob] * a.out2_cs + a.out2_c0 + (cb - a.out2_split)) = v;
+              else *reinterpret_cast<f32x4*>(a.out + pixs[sgrp][ob] * a.out_cs + a.out_c0 + cb) = v;
+            }
           }
       }
     }
@@ -1032,7 +1041,8 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return -2;
   bool (&attr)[3][4] = attr_dev[dev_];
   if (a.pre && (version != 2 || a.res1 || a.res2 || ((a.pre_cs | a.pre_c0) & 3) || (reinterpret_cast<uintptr_t>(a.pre) & 15))) return -6;
-  if (a.out2 && (version != 4 || a.res1 || ((a.out2_cs | a.out2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out2) & 15))) return -6;
+  if (a.out2 && (a.res1 || a.pre || ((a.out2_cs | a.out2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out2) & 15))) return -6;
+  if (a.out2 && version != 4 && (version != 2 || a.ntile_n != 1 || a.out2_split != 16)) return -6;
   if (a.f_w && (version != 4 || a.res1 || a.res2 || a.out2 || !a.f_bias || !a.f_scale || (reinterpret_cast<uintptr_t>(a.f_w) & 15))) return -6;
   const int res = (a.pre || a.f_w) ? 3 : a.res2 ? 2 : a.res1 ? 1 : 0;
   const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;

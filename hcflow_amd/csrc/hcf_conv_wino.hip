@@ -138,7 +138,10 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
     if (a.res1.p || a.res2.p || a.out2.p || !a.bias2 || !a.scale2) return HCF_ERR_UNSUPPORTED;
     w.f_w = reinterpret_cast<const char*>(a.wf1x1); w.f_bias = a.bias2; w.f_scale = a.scale2; w.f_act = a.act2;
   }
-  if (a.out2.p) { w.out2 = a.out2.p; w.out2_cs = a.out2.cs; w.out2_c0 = a.out2.c0; w.act2 = a.act_t2; }
+  if (a.out2.p) {
+    w.out2 = a.out2.p; w.out2_cs = a.out2.cs; w.out2_c0 = a.out2.c0; w.act2 = a.act_t2;
+    w.out2_split = (w.ntile_n == 1) ? 16 : 0;          // one 32-channel tile: its upper half (a 16-channel dense block's fat launch)
+  }
   if (a.res2.p) {
     if (!a.res1.p || a.res1_pre) return HCF_ERR_UNSUPPORTED;
     w.res2 = a.res2.p; w.res2_cs = a.res2.cs; w.res2_c0 = a.res2.c0; w.rs2 = a.rs2;

@@ -612,7 +612,10 @@ struct hcf_engine {
     build_conv(r.c[4], p + ".conv5", nf + 4 * gc, nf, srcs2(nf, 4 * gc), ACT_NONE);
     r.fat[0] = r.fat[1] = false;
     static const bool no_fat = getenv("HCF_NO_FAT") != nullptr;          // A/B knob, read once
-    if (spec_mode || rc != HCF_OK || !wino_enabled || no_fat || gc != 32 || (nf & 15) || nf < 32) return;
+    // gc = 32: pairs as one 64-channel launch (tile 1 = the partial) + a 32 -> 32 completion. gc = 16 (the rescaling nets' trunks,
+    // round 4): pairs as one 32-channel launch whose upper half-tile is the partial + a 16 -> 16 completion in a zero-padded tile
+    // -- instead of four convs that each fill half of a 32-wide MFMA tile with padding.
+    if (spec_mode || rc != HCF_OK || !wino_enabled || no_fat || (gc != 32 && gc != 16) || (nf & 15) || nf < 32) return;
     for (int j = 0; j < 2 && rc == HCF_OK; ++j) {
       const std::string pa = p + ".conv" + std::to_string(2 * j + 1), pb = p + ".conv" + std::to_string(2 * j + 2);
       auto wa = params.find(pa + ".weight"), wb = params.find(pb + ".weight");
@@ -629,10 +632,16 @@ struct hcf_engine {
       pack_conv(r.ca[j], wab.data(), biasab.data(), nullptr, ka, 2 * gc, 3, srcs2(nf, 2 * j * gc), ACT_LRELU);
       std::vector<int> s1(1, gc);
       pack_conv(r.cb[j], wc.data(), bb->second.data.data(), nullptr, gc, gc, 3, s1, ACT_LRELU);
-      if (rc == HCF_OK && !r.cb[j].wpack_wino) {         // 32 input channels: below the general Winograd threshold, wanted here
+      if (rc == HCF_OK && !r.cb[j].wpack_wino) {         // 32 / 16 input channels: below the general Winograd threshold, wanted here
         std::vector<float> pkw;
         int one = gc;
-        if (pack_conv_weights_wino(wc.data(), gc, gc, &one, 1, pkw, 16)) r.cb[j].wpack_wino = upload(pkw);
+        if (gc == 32) {
+          if (pack_conv_weights_wino(wc.data(), gc, gc, &one, 1, pkw, 16)) r.cb[j].wpack_wino = upload(pkw);
+        } else {                                          // 16 -> 16 in a zero-padded 32-channel tile
+          std::vector<float> wp((size_t)32 * gc * 9, 0.f);
+          memcpy(wp.data(), wc.data(), wc.size() * sizeof(float));
+          if (pack_conv_weights_wino(wp.data(), gc, 32, &one, 1, pkw, 16)) { r.cb[j].wpack_wino = upload(pkw); r.cb[j].wino_ntile = 1; }
+        }
       }
       r.ca[j].wkey = pa + ".weight+" + pb + ".weight[:, :" + std::to_string(ka) + "]";
       r.cb[j].wkey = pb + ".weight[:, " + std::to_string(ka) + ":]";
@@ -1078,10 +1087,12 @@ struct hcf_engine {
     // 61 + 79 at 16 x 160^2) -> up to 200 x 200 pixels per sample. The rule looks at the SAMPLE size, not at the batch: a sample's
     // bits must not depend on how many others share its launch (tests/test_gpu_nets.py: batch independence).
     const bool fat_ok = fatp && fatp->p && use_f16 && !taping && !fat_stale && !wino_stale && !(g_f16x3_ablation & 256) &&
-                        conv_wino_rounds_ok(B_, H, W, 2) && conv_wino_rounds_ok(B_, H, W, 1) &&
+                        (gc == 16 || conv_wino_rounds_ok(B_, H, W, 2)) && conv_wino_rounds_ok(B_, H, W, 1) &&
                         wino_offsets_ok(H, W, std::max(std::max(xin.cs, grow.cs), fatp->cs));
     static const long long fat12_pixels = getenv("HCF_FAT12_PIXELS") ? atoll(getenv("HCF_FAT12_PIXELS")) : 40000;   // experiment knob
-    const bool use_fat[2] = {fat_ok && r.fat[0] && (long long)H * W <= fat12_pixels, fat_ok && r.fat[1]};
+    // (16-channel blocks: both halves of a pair run on the 32-channel kernel, whose fixed cost the per-conv schedule pays too:
+    //  pair (1, 2) at every size)
+    const bool use_fat[2] = {fat_ok && r.fat[0] && (gc == 16 || (long long)H * W <= fat12_pixels), fat_ok && r.fat[1]};
     if (use_fat[0] || use_fat[1]) {
       const View none = mkview(nullptr, 0, 0, 0);
       for (int j = 0; j < 2; ++j) {

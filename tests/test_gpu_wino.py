@@ -91,6 +91,7 @@ def test_engine_uses_winograd_for_the_deep_dense_block_convs():
     from tests.test_gpu_nets import build_net
     cfg = preset("SR_4X_tiny")
     net = build_net(cfg, cached_params("SR_4X_tiny", 11)).set_precision("exact")      # the comparisons below start from the exact kernels
+    net.invalidate()          # (a cached net that has been through a device-side refresh keeps the per-conv schedule until re-finalised)
     g = torch.Generator().manual_seed(5)
     B, size = 2, 40
     lr = torch.rand(B, 3, size, size, generator=g).cuda()
@@ -127,6 +128,7 @@ def test_engine_runs_conditional_fcn_conv1_conv2_on_the_winograd_kernel():
     from tests.test_gpu_nets import build_net
     cfg = preset("SR_4X_tiny")
     net = build_net(cfg, cached_params("SR_4X_tiny", 11)).set_precision("exact")      # the comparisons below start from the exact kernels
+    net.invalidate()          # (a cached net that has been through a device-side refresh keeps the per-conv schedule until re-finalised)
     g = torch.Generator().manual_seed(6)
     B, h, w = 2, 37, 50                       # ragged against the 8 x 32 units
     lr = torch.rand(B, 3, h, w, generator=g).cuda()
@@ -165,6 +167,7 @@ def test_engine_runs_denseblock_coupling_convs_on_the_winograd_kernels():
     from tests.test_gpu_nets import build_net
     cfg = preset("Rescaling_4X_tiny")
     net = build_net(cfg, cached_params("Rescaling_4X_tiny", 13)).set_precision("exact")
+    net.invalidate()
     g = torch.Generator().manual_seed(8)
     hr = torch.rand(2, 3, 136, 200, generator=g).cuda()                 # ragged against the 16 x 32 units at both levels
     n_dense = sum(cfg.K[:cfg.L]) - sum(cfg.after)                       # DenseBlock steps per pass
@@ -194,3 +197,39 @@ def test_engine_runs_denseblock_coupling_convs_on_the_winograd_kernels():
     # the quantised LR image: a level may flip where the pre-quantisation value sits on a rounding boundary
     for x in (lr_a, lr_d):
         assert float(((x - lr_e).abs() > 0.5 / 255).float().mean()) <= 1e-3
+
+
+def test_engine_runs_16_channel_dense_blocks_as_fat_pairs():
+    """Rescaling nets (RRDB_gc = 16, Basic.py:360-377): four growth convs that each fill HALF of a 32-wide MFMA tile become two fat
+    pairs -- conv 2j+1 + the old-input part of conv 2j+2 as ONE 32-channel Winograd launch whose upper half-tile is stored raw
+    (Args::out2_split = 16), and a 16 -> 16 completion (one K chunk, zero-padded tile) that adds it before the activation (kind 7).
+    Launch counts, and the passes stay within the f16x3 tolerance of the exact kernels."""
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, maxdiff
+    from tests.test_gpu_nets import build_net
+    cfg = preset("Rescaling_4X_tiny")
+    assert cfg.rrdb_gc == 16
+    net = build_net(cfg, cached_params("Rescaling_4X_tiny", 13)).set_precision("exact")
+    net.invalidate()
+    g = torch.Generator().manual_seed(9)
+    hr = torch.rand(2, 3, 136, 200, generator=g).cuda()                 # ragged against the 16 x 32 units at both levels
+    n_rdb = 3 * (cfg.rrdb_nb[0] + cfg.rrdb_nb[1]) * cfg.L               # dense blocks per pass (both levels)
+    with torch.no_grad():
+        lr_e = net(hr=hr, reverse=False)[0]
+        rec_e = net(lr=lr_e, reverse=True, eps_std=0.0)
+        net.set_precision("f16x3")
+        try:
+            eng = net.engine()
+            eng.profile_convs(True)
+            lr_f = net(hr=hr, reverse=False)[0]
+            _, n7, _, _ = eng.conv_time(9, 1, kind=7, reset=True)
+            rec_f = net(lr=lr_e, reverse=True, eps_std=0.0)
+            _, m7, _, _ = eng.conv_time(9, 1, kind=7, reset=True)
+            eng.profile_convs(False)
+            assert eng.fallback_count() == 0
+        finally:
+            net.set_precision("exact")
+    assert (n7, m7) == (2 * n_rdb, 2 * n_rdb), (n7, m7, n_rdb)
+    assert maxdiff(lr_f, lr_e) <= 1.0 / 255 + 1e-6                       # quantised LR^: at most a single level flips
+    assert float(((lr_f - lr_e).abs() > 1e-6).float().mean()) < 0.01
+    assert maxdiff(rec_f, rec_e) <= 2e-5 * max(1.0, float(rec_e.abs().max()))
