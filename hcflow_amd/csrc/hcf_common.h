@@ -72,6 +72,12 @@ struct ConvArgs {
   // Winograd kernels only: the pack's channel tiles (1 / 2) when the real output width is not 32 / 64 (a DenseBlock coupling net's
   // last conv: 3 .. 42 channels, computed as a zero-padded tile and stored up to the next multiple of 4); 0: out.n / 32
   int wino_ntile;
+  // f16x3 kernel, training (gather-form data gradient of a dense block, hcf_engine_train.inc): this conv's output IS the complete
+  // dL/dy of the conv that produced `fb_y`; its epilogue applies that conv's epilogue backward on the spot -- out = dL/dpre =
+  // dL/dy * act'(y) (activation fb_act, no residuals, unit scale) -- and leaves what conv_epilogue_bwd_kernel would: per-block partial
+  // sums of dL/dpre per channel in fb_part ([grid blocks][2][n]; the second row stays zero), max |dL/dpre| in fb_max, and
+  // max(|dL/dpre|, *in_max) in fb_max2 (a slot OTHER than in_max, which every block of this launch reads: the running max moves on).
+  View fb_y; int fb_act; float* fb_part; float* fb_max; float* fb_max2;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
@@ -196,6 +202,8 @@ struct EpiBwdArgs {
   float* absmax;           // nullable: max |gpre| as float bits (atomicMax on the int view; zero-initialised)
   float* absmax2;          // nullable: a second slot raised the same way (shared by the convs of one dense block: the running
                            // max over the gradients a gather-form data-gradient conv reads, hcf_engine_train.inc)
+  const float* carry2;     // nullable: a slot whose value is folded into absmax2 as well (the running max so far: the next conv of the
+                           // dense block reads absmax2 while later kernels raise their own slot, so the running max moves slot to slot)
   float* part;             // per-block partial sums [conv_epilogue_bwd_blocks()][2][gy.n] (sum_pre, sum_zy): reduced in a fixed
                            // order by launch_sum_jobs, so parameter gradients are bit-reproducible; nullptr: fp32 atomics into sum_*
 };

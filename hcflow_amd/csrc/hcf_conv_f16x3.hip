@@ -188,8 +188,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const gf4ptr wq = (gf4ptr)uniform_ptr(a.wpack) + tid;   // this thread's float4 lane of the weight stream
   const gfptr zpage = uniform_ptr(a.zeros);
   float in_s = 1.f, out_s = 1.f;                 // SCALED: x * in_s lands in [2^9, 2^10] at the tensor's max |x|
+  int in_max_bits = 0;
   if (SCALED) {
-    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.in_max)));
+    in_max_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.in_max));
+    const float mx = __builtin_bit_cast(float, in_max_bits);
     if (mx > 0.f && mx < 3.0e38f) {
       int ex = 0;
       (void)frexpf(mx, &ex);                     // mx = m * 2^ex, m in [0.5, 1)
@@ -492,6 +494,10 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       constexpr int C4 = NPAD / 4;
       const int n4 = a.out.n >> 2;
       const bool h1 = a.res1.p != nullptr, h2 = a.res2.p != nullptr;
+      const bool fb = SCALED && a.fb_y.p != nullptr;        // fused epilogue backward of the conv whose dL/dy this is (ConvArgs::fb_y)
+      const float fb_neg = a.fb_act == ACT_RELU ? 0.f : a.fb_act == ACT_LRELU ? 0.2f : 1.f;
+      f32x4 fb_sum = {0.f, 0.f, 0.f, 0.f};
+      float fb_mx = 0.f;
 #pragma unroll 2
       for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
         const int idx = tid + NTHR * k;
@@ -502,7 +508,43 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
           const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
           if (h1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
           if (h2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
+          if (fb) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(a.fb_y.p + pixo * a.fb_y.cs + a.fb_y.c0 + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool pos = a.fb_act == ACT_RELU ? (yv[e] > 0.f) : (yv[e] >= 0.f);      // as conv_epilogue_bwd_kernel
+              v[e] = pos ? v[e] : v[e] * fb_neg;
+              fb_sum[e] += v[e];
+              fb_mx = fmaxf(fb_mx, fabsf(v[e]));
+            }
+          }
           *reinterpret_cast<f32x4*>(a.out.p + pixo * a.out.cs + a.out.c0 + 4 * c4) = v;
+        }
+      }
+      if (fb) {
+        // every thread owns ONE channel quad (NTHR % C4 == 0) of TH * TW * C4 / NTHR pixels: per-channel sums over the block's
+        // threads in a fixed order through LDS, one row of partials per block (reduced later by launch_sum_jobs)
+        static_assert(NTHR % C4 == 0, "one channel quad per thread");
+        __syncthreads();                               // the tile in LDS has been read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ldsT[tid * 4 + e] = fb_sum[e];
+        int* const fb_shm = reinterpret_cast<int*>(ldsT + NTHR * 4);      // (a word of the tile buffer: no extra static LDS)
+        if (tid == 0) *fb_shm = 0;
+        __syncthreads();
+        if (fb_mx > 0.f && fb_mx == fb_mx) atomicMax(fb_shm, __builtin_bit_cast(int, fb_mx));
+        const int n = a.out.n;
+        if (tid < n) {
+          const int q4 = tid >> 2, e = tid & 3;
+          float t0 = 0.f;
+          for (int j = 0; j < NTHR / C4; ++j) t0 += ldsT[(j * C4 + q4) * 4 + e];
+          a.fb_part[((size_t)blockIdx.x * 2 + 0) * n + tid] = t0;
+          a.fb_part[((size_t)blockIdx.x * 2 + 1) * n + tid] = 0.f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const int m = *fb_shm, m2 = max(m, in_max_bits);      // fb_max2: the running max, carried on from in_max's slot
+          if (a.fb_max && m) atomicMax(reinterpret_cast<int*>(a.fb_max), m);
+          if (a.fb_max2 && m2) atomicMax(reinterpret_cast<int*>(a.fb_max2), m2);
         }
       }
       done_vec = true;
@@ -570,6 +612,10 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
     b.vec_epi = !tall && !(a.tC > 0) && a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2) &&
                 !(g_f16x3_ablation & 64);                                      // --ablate 64: scalar epilogue
+  }
+  if (a.fb_y.p) {      // fused epilogue backward: the scaled, vector-epilogue variant only, 16-byte addressable y, whole channel quads
+    auto v4b = [](const View& v) { return (((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0); };
+    if (!a.in_max || a.fb_max2 == a.in_max || !b.vec_epi || !a.fb_part || !v4b(a.fb_y) || (a.out.n & 3) || a.out.n > 32 * NTB) return HCF_ERR_UNSUPPORTED;
   }
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);

@@ -48,9 +48,12 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const EpiBwdArgs
     __syncthreads();
     if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
     __syncthreads();
-    if (threadIdx.x == 0 && shm) {
-      atomicMax(reinterpret_cast<int*>(a.absmax), shm);
-      if (a.absmax2) atomicMax(reinterpret_cast<int*>(a.absmax2), shm);
+    if (threadIdx.x == 0) {
+      if (shm) atomicMax(reinterpret_cast<int*>(a.absmax), shm);
+      if (a.absmax2) {
+        const int c = (a.carry2 && blockIdx.x == 0) ? max(shm, *reinterpret_cast<const int*>(a.carry2)) : shm;
+        if (c) atomicMax(reinterpret_cast<int*>(a.absmax2), c);
+      }
     }
   }
   if (a.sum_pre || a.sum_zy) {
@@ -138,9 +141,12 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_vec_kernel(const EpiBwd
     __syncthreads();
     if (mx > 0.f && mx == mx) atomicMax(&shm, __builtin_bit_cast(int, mx));
     __syncthreads();
-    if (threadIdx.x == 0 && shm) {
-      atomicMax(reinterpret_cast<int*>(a.absmax), shm);
-      if (a.absmax2) atomicMax(reinterpret_cast<int*>(a.absmax2), shm);
+    if (threadIdx.x == 0) {
+      if (shm) atomicMax(reinterpret_cast<int*>(a.absmax), shm);
+      if (a.absmax2) {
+        const int c = (a.carry2 && blockIdx.x == 0) ? max(shm, *reinterpret_cast<const int*>(a.carry2)) : shm;
+        if (c) atomicMax(reinterpret_cast<int*>(a.absmax2), c);
+      }
     }
   }
   if (a.sum_pre || a.sum_zy) {

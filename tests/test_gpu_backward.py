@@ -516,3 +516,48 @@ def test_dense_block_gather_form_data_gradients_equal_the_per_conv_form(precisio
         for a, b in zip(g0, g1):
             assert np.isfinite(a).all()
             assert float(np.abs(a - b).max()) <= 2e-4 * max(float(np.abs(b).max()), 2e-5 * gmax)
+
+
+def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(monkeypatch):
+    """f16x3 training: the gather conv of x_m (m >= 1) applies the epilogue backward of the conv that produced x_m in its own
+    epilogue (ConvArgs::fb_y, hcf_engine_train.inc rdb_fuse_ok). dL/dpre is the same fp32 product either way, so weight gradients
+    are equal bit for bit; bias gradients are sums over differently shaped blocks (rounding only). HCF_NO_EPI_FUSE=1 selects the
+    separate conv_epilogue_bwd launch, read at the start of each backward pass."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, spec_grads
+    cfg = preset("SR_4X_tiny")
+    g = torch.Generator().manual_seed(33)
+    hr = torch.rand(2, 3, 96, 160, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(cached_params("SR_4X_tiny", 11), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").train().set_precision("f16x3")
+    res = []
+    for off in (False, True, False):
+        if off:
+            monkeypatch.setenv("HCF_NO_EPI_FUSE", "1")
+        else:
+            monkeypatch.delenv("HCF_NO_EPI_FUSE", raising=False)
+        net.zero_grad(set_to_none=True)
+        _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+        nll.backward()
+        res.append((float(nll.detach()), spec_grads(net, cfg)))
+    (n0, g0), (n1, g1), (n2, g2) = res
+    assert n0 == n1 == n2
+    for a, c in zip(g0, g2):
+        assert np.array_equal(a, c)                       # the fused form is reproducible run to run
+    ndiff = 0
+    for a, b in zip(g0, g1):
+        assert np.isfinite(a).all()
+        if a.ndim >= 2:
+            assert np.array_equal(a, b)
+        else:
+            ndiff += int(not np.array_equal(a, b))
+            assert float(np.abs(a - b).max()) <= 2e-6 * max(float(np.abs(b).max()), 1e-30)
+    assert ndiff > 0                                      # the knob did select another summation order
