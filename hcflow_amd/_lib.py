@@ -33,7 +33,7 @@ SYMBOLS = [
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
     "hcf_train_select_tape", "hcf_train_forward_rescale", "hcf_train_backward_rescale",
     "hcf_debug_range_probe", "hcf_debug_range_probe_read",
-    "hcf_aux_conv2d_workspace", "hcf_aux_conv2d", "hcf_aux_conv2d_backward",
+    "hcf_aux_conv2d_workspace", "hcf_aux_conv2d", "hcf_aux_conv2d_backward", "hcf_adam_step",
 ]
 
 
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
     lib.hcf_train_select_tape.argtypes = [vp, i32]
     lib.hcf_train_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, C.c_uint32, vp]
     lib.hcf_train_backward_rescale.argtypes = [vp, fp, fp, fp, fp, i64, vp]
+    lib.hcf_adam_step.argtypes = [vp, vp, vp, vp, i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64, vp]
     lib.hcf_aux_conv2d_workspace.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.hcf_aux_conv2d_workspace.restype = C.c_size_t
     lib.hcf_aux_conv2d.argtypes = [fp, i32, i32, i32, i32, i32, fp, fp, i32, i32, i32, fp, i32, vp, C.c_size_t, i32, vp]

@@ -225,6 +225,23 @@ int hcf_profile_convs(hcf_engine* e, int enable);
 int hcf_conv_time_ms(hcf_engine* e, int32_t taps, int32_t nt, int32_t kind, int32_t reset, double* total_ms,
                      int64_t* launches, double* flops, double* bytes);
 
+/* ---- the optimiser step of the training caller (reference: HCFlow_SR_model.py:118-120 / HCFlow_Rescaling_model.py:140-142
+ * build torch.optim.Adam(optim_params, lr, weight_decay, betas) over netG's ~1500 parameter tensors and step it once per
+ * iteration, optimize_parameters :202) as ONE launch. param / exp_avg / exp_avg_sq: device fp32 buffers of one layout (every
+ * parameter tensor in a slot at a multiple-of-4 offset; 16-byte aligned bases). chunks_dev: DEVICE table, one entry per
+ * <= HCF_ADAM_CHUNK consecutive elements of a tensor: its gradient slice (device fp32, any alignment), the slot offset
+ * (floats, multiple of 4) and the length. Arithmetic of torch.optim.Adam with amsgrad = False, maximize = False, L2 weight
+ * decay: g += wd p; m += (g - m)(1 - beta1); v = v beta2 + (1 - beta2) g g; p -= lr / (1 - beta1^step) * m /
+ * (sqrt(v) / sqrt(1 - beta2^step) + eps); step >= 1 is the count AFTER this update. Enqueues on `stream`, no sync. */
+#define HCF_ADAM_CHUNK 4096
+typedef struct hcf_adam_chunk {
+  const float* grad;
+  uint32_t offset;
+  uint32_t n;
+} hcf_adam_chunk;
+int hcf_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const hcf_adam_chunk* chunks_dev, int32_t n_chunks,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step, hcf_stream_t stream);
+
 /* ---- validation metrics around the path (reference: the per-image metric block of test_HCFlow.py:103-182) ------
  * hcf_metric_psnr_ssim: util.tensor2img (utils/util.py:790-816) on gt and sr, then util.calculate_psnr_ssim(gt, sr,
  * crop_border) (:898-982; Y channel as data/util.py:209-230) and, for scale > 1, the same on

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--hr", type=int, default=160)
     ap.add_argument("--preset", default="SR_DF2K_4X")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "exact"])
+    ap.add_argument("--optim", default="torch", choices=["torch", "native", "torch-fused"],
+                    help="torch: torch.optim.Adam + torch clip_grad_norm_ as the reference's caller; native: hcflow_amd.optim")
     args = ap.parse_args()
     cfg = preset(args.preset)
     with contextlib.redirect_stdout(sys.stderr):
@@ -34,7 +36,13 @@ def main():
     B, H = args.batch, args.hr
     hr = torch.rand(B, 3, H, H, generator=g).cuda()
     lr = torch.nn.functional.interpolate(hr, scale_factor=1.0 / cfg.scale, mode="bicubic", align_corners=False).clamp(0, 1)
-    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2.5e-4, betas=(0.9, 0.99))
+    ps = [p for p in net.parameters() if p.requires_grad]
+    if args.optim == "native":
+        from hcflow_amd import optim as hopt
+        opt, clip = hopt.Adam(ps, lr=2.5e-4, betas=(0.9, 0.99)), hopt.clip_grad_norm_
+    else:
+        opt = torch.optim.Adam(ps, lr=2.5e-4, betas=(0.9, 0.99), **({"fused": True} if args.optim == "torch-fused" else {}))
+        clip = torch.nn.utils.clip_grad_norm_
     sync = torch.cuda.synchronize
     rows = []
     for it in range(args.steps + 1):
@@ -44,7 +52,7 @@ def main():
         sync(); t1 = time.perf_counter()
         nll.backward()
         sync(); t2 = time.perf_counter()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 100.0)
+        clip(net.parameters(), 100.0)
         opt.step()
         sync(); t3 = time.perf_counter()
         rows.append((1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), float(nll.detach())))
