@@ -122,6 +122,10 @@ struct WgradArgs {
   float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
   size_t part_cap;         // capacity of `part` in floats
   int cin_total, tpb;      // set by the launcher
+  int strip_w;             // set by the launcher (f16x3 kernel): 0, or W + 1: the tiles walk STRIPS -- the B images of a tile row side
+  unsigned strip_magic;    // by side with one zero column between them (virtual width B (W + 1)) -- instead of every image's own
+                           // ceil(W / 32) tiles: a 40-wide image fills 40 of 64 tile columns, the strip 640 of 656. Pixels are the
+                           // reduction dimension here, so only the walk changes. strip_magic = 2^32 / strip_w + 1 (exact division).
   int dbg;                 // timing ablations (HCF_WG_DBG): 1 no MFMAs, 2 no epilogue, 4 no global loads
 };
 size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int* tpb = nullptr);

@@ -253,8 +253,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = a.H, W = a.W;
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int ntiles = a.B * tiles_x * tiles_y;
+  const int sw = a.strip_w, svw = a.B * sw;      // strips (WgradArgs::strip_w): virtual row width B (W + 1)
+  const unsigned smagic = a.strip_magic;
+  const int tiles_x = sw ? (svw + TW - 1) / TW : (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = sw ? tiles_x * tiles_y : a.B * tiles_x * tiles_y;
 
   int blk = blockIdx.y, si = 0;
   for (; si < a.nsrc; ++si) {
@@ -297,14 +299,22 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
   const float* const gbase = a.g.p + a.g.c0 + oc0;
 #define HCF_WG_LOAD(TILE)                                                                                     \
   {                                                                                                           \
-    const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, b_ = (TILE) / (tiles_x * tiles_y); \
+    const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y, bt_ = sw ? 0 : (TILE) / (tiles_x * tiles_y); \
     const int x0_ = txb_ * TW, y0_ = tyb_ * TH;                                                               \
     mskx = 0;                                                                                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < NX; ++s_) {                                                       \
       const int hp = min((tid + 512 * s_) >> 3, HP - 1);                                                      \
       const int hy = hp / HW, hx = hp - hy * HW;                                                              \
-      const int y = y0_ + hy - PAD, x = x0_ + hx - PAD;                                                       \
-      mskx |= (y >= 0 && y < H && x >= 0 && x < W) ? (1u << s_) : 0u;                                         \
+      const int y = y0_ + hy - PAD;                                                                           \
+      int x = x0_ + hx - PAD, b_ = bt_;                                                                       \
+      bool okx_ = x >= 0 && x < W;                                                                            \
+      if (sw) {                      /* virtual column -> (image, column); column W is the zero separator */ \
+        const int vc_ = min(max(x, 0), svw - 1);                                                              \
+        b_ = (int)__umulhi((unsigned)vc_, smagic);                                                            \
+        okx_ = x >= 0 && x < svw && (vc_ - b_ * sw) < W;                                                      \
+        x = vc_ - b_ * sw;                                                                                    \
+      }                                                                                                       \
+      mskx |= (y >= 0 && y < H && okx_) ? (1u << s_) : 0u;                                                    \
       const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                           \
       const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                            \
       f32x4 v;                                                                                                \
@@ -319,8 +329,16 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
     mskg = 0;                                                                                                 \
     _Pragma("unroll") for (int s_ = 0; s_ < NG; ++s_) {                                                       \
       const int px = (tid + 512 * s_) >> 3;                                                                   \
-      const int y = y0_ + (px >> 5), x = x0_ + (px & 31);                                                     \
-      mskg |= (y < H && x < W) ? (1u << s_) : 0u;                                                             \
+      const int y = y0_ + (px >> 5);                                                                          \
+      int x = x0_ + (px & 31), b_ = bt_;                                                                      \
+      bool okx_ = x < W;                                                                                      \
+      if (sw) {                                                                                               \
+        const int vc_ = min(x, svw - 1);                                                                      \
+        b_ = (int)__umulhi((unsigned)vc_, smagic);                                                            \
+        okx_ = x < svw && (vc_ - b_ * sw) < W;                                                                \
+        x = vc_ - b_ * sw;                                                                                    \
+      }                                                                                                       \
+      mskg |= (y < H && okx_) ? (1u << s_) : 0u;                                                              \
       const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;       \
       f32x4 v;                                                                                                \
       if (VEC) {                                                                                              \
@@ -536,11 +554,23 @@ int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
+// Tiles the kernels walk; *strip_w: WgradArgs::strip_w of the f16x3 kernel (strips when they save >= 10 % of the tiles).
+static int wgrad_tiles(const WgradArgs& a0, int* strip_w) {
+  const int tiles_y = (a0.H + 7) / 8, per_image = a0.B * ((a0.W + 31) / 32) * tiles_y;
+  if (strip_w) *strip_w = 0;
+  const bool off = getenv("HCF_NO_WG_STRIP") != nullptr;             // A/B knob
+  if (!a0.g_max || off || a0.B < 2 || (long long)a0.B * (a0.W + 1) >= 65536) return per_image;
+  const int strips = ((a0.B * (a0.W + 1) + 31) / 32) * tiles_y;
+  if (strips * 10 > per_image * 9) return per_image;
+  if (strip_w) *strip_w = a0.W + 1;
+  return strips;
+}
+
 size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_tpb) {
   int nicb = 0;
   for (int i = 0; i < a0.nsrc; ++i) nicb += (a0.src[i].n + 31) >> 5;
   const int nocb = (a0.g.n + 31) >> 5;
-  const int tiles = a0.B * ((a0.W + 31) / 32) * ((a0.H + 7) / 8);
+  const int tiles = wgrad_tiles(a0, nullptr);
   const int pairs = nicb * nocb;
   // fp32 kernel: one resident round of 256 CUs x 2 blocks (measured best of 512 / 768 / 1024 / 2048; phase-aligned rounds do
   // not overlap). The f16x3 kernel holds one 8-wave block per CU (92 KB of LDS).
@@ -582,6 +612,8 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer
   a.cin_total = cin;
   int nblk_x = 0;
   const size_t need = conv_wgrad_scratch_floats(a, &nblk_x, &a.tpb);
+  (void)wgrad_tiles(a, &a.strip_w);
+  a.strip_magic = a.strip_w ? (unsigned)(0x100000000ull / (unsigned)a.strip_w) + 1u : 0u;
   if (need > a.part_cap) return HCF_ERR_NOMEM;
   const int nocb = (a.g.n + 31) >> 5;
   const dim3 grid((unsigned)nblk_x, (unsigned)nicb, (unsigned)nocb);

@@ -53,6 +53,36 @@ def test_conv2d_backward(case, precision):
     assert _rel(db, b64.grad) <= 1e-6
 
 
+@pytest.mark.parametrize("shape", [(16, 40, 40, [64, 32], [0, 0], 32), (5, 20, 20, [32], [0], 64), (3, 9, 33, [64], [0], 32),
+                                   (4, 16, 24, [16, 32], [0, 1], 32), (7, 8, 1, [32], [0], 32)])
+def test_conv2d_weight_gradient_f16x3_strips(shape, monkeypatch):
+    """Narrow images: the f16x3 weight-gradient kernel walks STRIPS (the B images of a tile row side by side with one zero
+    column between them, WgradArgs::strip_w) instead of every image's own tiles -- the same sum over pixels in another order.
+    Against fp64, against the per-image walk (HCF_NO_WG_STRIP=1), and reproducible."""
+    from hcflow_amd import ops
+    B, H, W, cs, ups, cout = shape
+    g = _gen(B * 1000 + W)
+    srcs = [torch.randn(B, c, H >> u, W >> u, generator=g) for c, u in zip(cs, ups)]
+    gy = torch.randn(B, cout, H, W, generator=g)
+    x = torch.cat([F.interpolate(s, scale_factor=2 ** u, mode="nearest") if u else s for s, u in zip(srcs, ups)], 1).double()
+    ref = torch.nn.grad.conv2d_weight(x, (cout, sum(cs), 3, 3), gy.double(), stride=1, padding=1)
+    w0 = torch.zeros(cout, sum(cs), 3, 3)
+    ops.set_precision("f16x3")
+    try:
+        res = []
+        for off in (False, False, True):
+            if off:
+                monkeypatch.setenv("HCF_NO_WG_STRIP", "1")
+            else:
+                monkeypatch.delenv("HCF_NO_WG_STRIP", raising=False)
+            res.append(ops.conv2d_backward([s.cuda() for s in srcs], w0, gy.cuda(), ups, need_input_grads=False)[1].cpu())
+    finally:
+        ops.set_precision("exact")
+    assert torch.equal(res[0], res[1])
+    assert _rel(res[0], ref) <= 3e-6 and _rel(res[2], ref) <= 3e-6
+    assert _rel(res[0], res[2]) <= 2e-6
+
+
 @pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e4])
 def test_conv2d_weight_gradient_f16x3_ranges(gscale):
     """The f16 matrix-core weight gradient (hcf_conv_wgrad.hip, conv_wgrad_f16x3_kernel) scales G by a power of two taken
