@@ -78,7 +78,13 @@ struct ConvArgs {
   // sums of dL/dpre per channel in fb_part ([grid blocks][2][n]; the second row stays zero), max |dL/dpre| in fb_max, and
   // max(|dL/dpre|, *in_max) in fb_max2 (a slot OTHER than in_max, which every block of this launch reads: the running max moves on).
   View fb_y; int fb_act; float* fb_part; float* fb_max; float* fb_max2;
+  // set by the f16x3 launcher (scaled training variant only): 0, or W + 1 -- the 8 x 32 tiles walk STRIPS, the B images of a tile
+  // row side by side with one zero column between them, instead of every image's own ceil(W / 32) tiles (narrow images: a 40-wide
+  // image fills 40 of 64 tile columns, the strip 640 of 656). strip_magic = 2^32 / strip_w + 1 (exact division of < 2^16).
+  int strip_w; unsigned strip_magic;
 };
+// grid of the scaled f16x3 variant for a [B, H, W] tensor (= rows of ConvArgs::fb_part), strips included
+int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w = nullptr);
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 // Branch-free activation for unrolled epilogues: a runtime `if (act == ...)` chain per accumulator compiles to a chain of

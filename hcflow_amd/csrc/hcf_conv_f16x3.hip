@@ -76,6 +76,17 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle 
 // a dx-major sliding-window tap loop (fewer LDS reads, same time), a pre-split activation format with register staging,
 // persistent blocks with the next tile's first chunk prefetched (VGPR cap: spills), a first-round block stagger.
 
+int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w) {
+  const int tiles_y = (H + 7) / 8, per_image = B * ((W + 31) / 32) * tiles_y;
+  if (strip_w) *strip_w = 0;
+  const bool off = getenv("HCF_NO_DG_STRIP") != nullptr;             // A/B knob
+  if (off || B < 2 || (long long)B * (W + 1) >= 65536) return per_image;
+  const int strips = ((B * (W + 1) + 31) / 32) * tiles_y;
+  if (strips * 10 > per_image * 9) return per_image;
+  if (strip_w) *strip_w = W + 1;
+  return strips;
+}
+
 namespace f16x3 {
 
 constexpr int KC = 16;
@@ -151,11 +162,13 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int wm = (NTB == 2) ? (wave >> 1) : wave;   // which group of MT tile rows
   const int wn = (NTB == 2) ? (wave & 1) : 0;       // which 32-channel n tile
   const int H = a.H, W = a.W;
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int sw = SCALED ? a.strip_w : 0, svw = a.B * sw;      // strips (ConvArgs::strip_w): virtual row width B (W + 1)
+  const unsigned smagic = a.strip_magic;
+  const int tiles_x = sw ? (svw + TW - 1) / TW : (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int txb = bid % tiles_x;
   const int tyb = (bid / tiles_x) % tiles_y;
-  const int b = bid / (tiles_x * tiles_y);
+  const int b = sw ? 0 : bid / (tiles_x * tiles_y);
   const int x0 = txb * TW, y0 = tyb * TH;
 
   int pos[NSLOT], pix0[NSLOT];
@@ -165,12 +178,20 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
     const int q = tid + NTHR * s;
     const int hp = min(q >> 2, HP - 1);
     const int hy = hp / HW, hx = hp - hy * HW;
-    const int y = y0 + hy - PAD, x = x0 + hx - PAD;
-    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+    const int y = y0 + hy - PAD;
+    int x = x0 + hx - PAD, bs = b;
+    bool okx = x >= 0 && x < W;
+    if (SCALED && sw) {                              // virtual column -> (image, column); column W is the zero separator
+      const int vc = min(max(x, 0), svw - 1);
+      bs = (int)__umulhi((unsigned)vc, smagic);
+      okx = x >= 0 && x < svw && (vc - bs * sw) < W;
+      x = vc - bs * sw;
+    }
+    const bool ok = y >= 0 && y < H && okx;
     okmask |= ok ? (1u << s) : 0u;
     const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
     pos[s] = (yc << 16) | xc;
-    pix0[s] = (b * H + yc) * W + xc;               // pixel index for sources read at full resolution
+    pix0[s] = (bs * H + yc) * W + xc;              // pixel index for sources read at full resolution
   }
   const int uq = tid & 3;
   const int u0 = (a.src[0].n + 3) >> 2;
@@ -502,10 +523,18 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
       for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
         const int idx = tid + NTHR * k;
         const int px = idx / C4, c4 = idx - px * C4;
-        const int y = y0 + (px >> 5), x = x0 + (px & 31);
+        const int y = y0 + (px >> 5);
+        int x = x0 + (px & 31), bo = b;
+        bool okx = x < W;
+        if (SCALED && sw) {
+          const int vc = min(x, svw - 1);
+          bo = (int)__umulhi((unsigned)vc, smagic);
+          okx = x < svw && (vc - bo * sw) < W;
+          x = vc - bo * sw;
+        }
         f32x4 v = *reinterpret_cast<const f32x4*>(ldsT + px * NPAD + 4 * c4);
-        if (y < H && x < W && c4 < n4) {
-          const size_t pixo = (size_t)((size_t)b * H + y) * W + x;
+        if (y < H && okx && c4 < n4) {
+          const size_t pixo = (size_t)((size_t)bo * H + y) * W + x;
           if (h1) v = v * a.rs1 + *reinterpret_cast<const f32x4*>(a.res1.p + pixo * a.res1.cs + a.res1.c0 + 4 * c4);
           if (h2) v = v * a.rs2 + *reinterpret_cast<const f32x4*>(a.res2.p + pixo * a.res2.cs + a.res2.c0 + 4 * c4);
           if (fb) {
@@ -603,11 +632,12 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   const bool tall = plain && (((g_f16x3_tall ^ g_f16x3_ablation) >> (NTB - 1)) & 1) && a.H >= 16;   // --ablate 1/2/3 turns it off
   const int THr = tall ? 16 : 8;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + THr - 1) / THr;
-  const long long nblk = (long long)a.B * tiles_x * tiles_y;
+  long long nblk = (long long)a.B * tiles_x * tiles_y;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;
   bool vec = true;
   ConvArgs b = a;
   b.any_up = 0;
+  b.strip_w = 0; b.strip_magic = 0;
   {
     auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
     b.vec_epi = !tall && !(a.tC > 0) && a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2) &&
@@ -650,8 +680,13 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
   else if (tall)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
-  else if (a.in_max && vec && !b.any_up)
+  else if (a.in_max && vec && !b.any_up) {
+    if (b.vec_epi) {                               // strips on narrow images (the vector epilogue maps pixels back per image)
+      nblk = conv_f16x3_scaled_blocks(a.B, a.H, a.W, &b.strip_w);
+      b.strip_magic = b.strip_w ? (unsigned)(0x100000000ull / (unsigned)b.strip_w) + 1u : 0u;
+    }
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  }
   else if (a.in_max)
     return HCF_ERR_UNSUPPORTED;
   else if (vec && !b.any_up)

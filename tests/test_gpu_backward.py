@@ -64,23 +64,31 @@ def test_conv2d_weight_gradient_f16x3_strips(shape, monkeypatch):
     g = _gen(B * 1000 + W)
     srcs = [torch.randn(B, c, H >> u, W >> u, generator=g) for c, u in zip(cs, ups)]
     gy = torch.randn(B, cout, H, W, generator=g)
-    x = torch.cat([F.interpolate(s, scale_factor=2 ** u, mode="nearest") if u else s for s, u in zip(srcs, ups)], 1).double()
-    ref = torch.nn.grad.conv2d_weight(x, (cout, sum(cs), 3, 3), gy.double(), stride=1, padding=1)
-    w0 = torch.zeros(cout, sum(cs), 3, 3)
+    s64 = [t.double().requires_grad_(True) for t in srcs]
+    x = torch.cat([F.interpolate(t, scale_factor=2 ** u, mode="nearest") if u else t for t, u in zip(s64, ups)], 1)
+    ref = torch.nn.grad.conv2d_weight(x.detach(), (cout, sum(cs), 3, 3), gy.double(), stride=1, padding=1)
+    w = torch.randn(cout, sum(cs), 3, 3, generator=g) / (9 * sum(cs)) ** 0.5
+    F.conv2d(x, w.double(), None, 1, 1).backward(gy.double())
     ops.set_precision("f16x3")
     try:
         res = []
         for off in (False, False, True):
-            if off:
-                monkeypatch.setenv("HCF_NO_WG_STRIP", "1")
-            else:
-                monkeypatch.delenv("HCF_NO_WG_STRIP", raising=False)
-            res.append(ops.conv2d_backward([s.cuda() for s in srcs], w0, gy.cuda(), ups, need_input_grads=False)[1].cpu())
+            for k in ("HCF_NO_WG_STRIP", "HCF_NO_DG_STRIP"):      # the scaled data-gradient conv walks strips as well
+                if off:
+                    monkeypatch.setenv(k, "1")
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            ds, dw, _ = ops.conv2d_backward([t.cuda() for t in srcs], w, gy.cuda(), ups)
+            res.append((dw.cpu(), [d.cpu() for d in ds]))
     finally:
         ops.set_precision("exact")
-    assert torch.equal(res[0], res[1])
-    assert _rel(res[0], ref) <= 3e-6 and _rel(res[2], ref) <= 3e-6
-    assert _rel(res[0], res[2]) <= 2e-6
+    assert torch.equal(res[0][0], res[1][0])
+    assert _rel(res[0][0], ref) <= 3e-6 and _rel(res[2][0], ref) <= 3e-6
+    assert _rel(res[0][0], res[2][0]) <= 2e-6
+    for d0, d1, d2, t in zip(res[0][1], res[1][1], res[2][1], s64):
+        assert torch.equal(d0, d1)
+        assert torch.equal(d0, d2)                 # per output pixel the same products in the same order: bit-equal to the per-image walk
+        assert _rel(d0, t.grad) <= 3e-6
 
 
 @pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e4])
