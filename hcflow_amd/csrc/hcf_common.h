@@ -127,6 +127,8 @@ struct WgradArgs {
   const float* g_max;      // nullable (device): max |g|; non-null selects the f16x3 matrix-core kernel (g scaled by a power of two)
   float* part;             // scratch for the per-block partial tiles, >= conv_wgrad_scratch_floats(a) floats
   size_t part_cap;         // capacity of `part` in floats
+  int blocks_hint;         // f16x3 kernel: blocks per launch to aim for (0: 256 = one per CU). The engine asks for 160 when the
+                           // weight gradients run on their own stream BESIDE the data-gradient chain, so the two do not share CUs
   int cin_total, tpb;      // set by the launcher
   int strip_w;             // set by the launcher (f16x3 kernel): 0, or W + 1: the tiles walk STRIPS -- the B images of a tile row side
   unsigned strip_magic;    // by side with one zero column between them (virtual width B (W + 1)) -- instead of every image's own

@@ -577,7 +577,7 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   static const int wg_blocks = getenv("HCF_WG_BLOCKS") ? atoi(getenv("HCF_WG_BLOCKS")) : 0;   // experiment knob, read once
   int nblk_x;
   if (a0.g_max) {                                   // at most one full round of 256 blocks (264 blocks would cost two)
-    const int target = wg_blocks > 0 ? wg_blocks : 256;
+    const int target = wg_blocks > 0 ? wg_blocks : (a0.blocks_hint > 0 ? a0.blocks_hint : 256);
     nblk_x = target / pairs;
   } else {
     nblk_x = ((wg_blocks > 0 ? wg_blocks : 512) + pairs - 1) / pairs;
