@@ -298,7 +298,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const int bbase = half * BHALF + (wn * 32 + li) * 16;
 
 #ifdef HCF_CONV_TIMERS
-  const bool dbg_on = a.dbg && (blockIdx.x & 1023) == 512 && tid == 0;     // a few mid-grid blocks
+  const bool dbg_on = a.dbg && (blockIdx.x & 1023) == (gridDim.x > 512 ? 512u : gridDim.x / 2) && tid == 0;     // a few mid-grid blocks
   const unsigned long long dbg_ra = dbg_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #endif
   HCF_STAGE_LOAD(0);

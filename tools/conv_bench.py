@@ -23,6 +23,10 @@ SHAPES = [
     ("fcn_conv2     64->64 1x1 @320", 16, 320, 320, [64], 64, 1),
     ("completion    32->32     @320", 16, 320, 320, [32], 32, 3),      # the direct kernel on the fat schedule's completion shape
     ("completion    32->32     @160", 16, 160, 160, [32], 32, 3),
+    # training sizes (config 5: B = 16, LR 40 x 40): the gather data-gradient shapes of a dense block, forward kernels
+    ("train dgrad x1 96+64->32  @40", 16, 40, 40, [96, 64], 32, 3),
+    ("train dgrad x4 64->32     @40", 16, 40, 40, [64], 32, 3),
+    ("train dgrad x0 128+64->64 @40", 16, 40, 40, [128, 64], 64, 3),
 ]
 
 
