@@ -88,12 +88,42 @@ class Adam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False, foreach=None,
                         capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
         super().__init__(params, defaults)
-        self._lib = _lib.load()
-        self._flat = [_Flat(g["params"]) for g in self.param_groups]
+        self._ensure()
+
+    def _ensure(self):
+        """The flat buffers (built with the optimiser; rebuilt from the parameters' current values in a copy that lost them:
+        ``torch.optim.Optimizer.__getstate__`` keeps defaults, state and param_groups only)."""
+        if "_flat" not in self.__dict__:
+            self._lib = _lib.load()
+            self._flat = [_Flat(g["params"]) for g in self.param_groups]
+            for g, fl in zip(self.param_groups, self._flat):      # moments that came along (unpickled state): into the flat buffers
+                for i, p in enumerate(g["params"]):
+                    st = self.state.get(p)
+                    if st and "exp_avg" in st:
+                        with torch.no_grad():
+                            m, v = fl.view(fl.M, i, p), fl.view(fl.V, i, p)
+                            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                        fl.t[i] = int(round(float(st.get("step", 0))))
+                        self.state[p] = {"exp_avg": m, "exp_avg_sq": v}
+        return self._flat
+
+    def __getstate__(self):
+        # what copy / pickle carry: torch's three entries, with each tensor's step count put back beside its moments (the live
+        # state keeps the counts in one array per group, not as ~1 500 scalar tensors to bump per step)
+        d = dict(super().__getstate__())
+        state = {}
+        for g, fl in zip(self.param_groups, self._ensure()):
+            for i, p in enumerate(g["params"]):
+                if p in self.state:
+                    ent = dict(self.state[p])
+                    ent["step"] = torch.tensor(float(fl.t[i]), dtype=torch.float32)
+                    state[p] = ent
+        d["state"] = state
+        return d
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
-        if hasattr(self, "_flat"):
+        if "_flat" in self.__dict__:
             self._flat.append(_Flat(self.param_groups[-1]["params"]))
 
     # ---- state in torch.optim.Adam's format ---------------------------------------------------------------------------------
@@ -106,7 +136,7 @@ class Adam(torch.optim.Optimizer):
     def state_dict(self):
         sd = super().state_dict()
         idx = 0
-        for g, fl in zip(self.param_groups, self._flat):
+        for g, fl in zip(self.param_groups, self._ensure()):
             for i, p in enumerate(g["params"]):
                 if idx in sd["state"]:
                     # copies: the live moments are slices of the flat buffers (a loader that keeps the tensors, as
@@ -120,7 +150,7 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         with torch.no_grad():
-            for g, fl in zip(self.param_groups, self._flat):
+            for g, fl in zip(self.param_groups, self._ensure()):
                 if g.get("amsgrad"):
                     raise ValueError("hcflow_amd.optim.Adam: the loaded state was trained with amsgrad=True")
                 for i, p in enumerate(g["params"]):
@@ -170,7 +200,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group, fl in zip(self.param_groups, self._flat):
+        for group, fl in zip(self.param_groups, self._ensure()):
             params = group["params"]
             state = self.state
             ptrs, active = [0] * len(params), []
@@ -180,7 +210,10 @@ class Adam(torch.optim.Optimizer):
                     continue
                 ptrs[i] = g.data_ptr()
                 active.append(i)
-                if p.data_ptr() != fl.pptr[i]:                  # someone re-pointed p.data (module.to(), a manual swap): take it back in
+                if p.data_ptr() != fl.pptr[i]:                  # someone re-pointed p.data (a manual swap, a cast and back): take it back in
+                    if p.device != fl.device or p.dtype != torch.float32 or p.numel() != fl.numel[i]:
+                        raise _lib.HcfError("hcflow_amd.optim.Adam: parameter %d is now %s %s; it was fp32 on %s when the optimiser "
+                                            "was built (build the optimiser after .to(device))" % (i, p.device, p.dtype, fl.device))
                     fl.adopt(p, fl.offs[i], fl.numel[i])
                 if p not in state:                              # first gradient, or the scheduler cleared the state on a restart
                     self._init_state(fl, i, p)

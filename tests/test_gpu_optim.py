@@ -197,3 +197,30 @@ def test_training_steps_of_a_drop_in_net_with_the_native_optimiser():
         assert abs(x - y) <= 1e-4 * abs(y)
     for x, y in zip(p0, p1):
         assert float(np.abs(x - y).max()) <= 1e-5 * max(float(np.abs(y).max()), 1e-3)
+
+
+def test_optimizer_survives_a_copy_and_refuses_moved_parameters():
+    """copy.deepcopy / pickle keep defaults, state and param_groups only (torch.optim.Optimizer.__getstate__): the flat buffers are
+    rebuilt from what came along. A parameter that left the GPU after the optimiser was built is an error, not a silent copy back."""
+    import copy
+    from hcflow_amd import _lib, optim
+    a, b = _twins(5)
+    mine = optim.Adam(a, lr=1e-3, betas=(0.9, 0.99))
+    ref = torch.optim.Adam(b, lr=1e-3, betas=(0.9, 0.99))
+    for it in range(2):
+        _set_grads(a, b, 700 + it)
+        mine.step(); ref.step()
+    twin = copy.deepcopy(mine)                       # its own parameter tensors (deep copies), moments and step counts
+    a2 = twin.param_groups[0]["params"]
+    for it in range(2):
+        _set_grads(a2, b, 710 + it)
+        twin.step(); ref.step()
+    for p, q in zip(a2, b):
+        _close(p, q)
+    for p, q in zip(a, a2):
+        assert not torch.equal(p, q)                 # the original did not move
+    _set_grads(a, b, 720, skip=(3,))
+    a[3].data = a[3].data.cpu()
+    a[3].grad = torch.ones_like(a[3])
+    with pytest.raises(_lib.HcfError):
+        mine.step()
