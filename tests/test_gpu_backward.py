@@ -263,6 +263,21 @@ def test_ddp_wrapped_module_trains():
         gmax = max(float(b.abs().max()) for b in want)
         for a, b in zip(got, want):
             assert float((a - b).abs().max()) <= 1e-4 * max(2e-5 * gmax, float(b.abs().max()))
+        # the reference builds its optimiser AFTER the DDP wrap (HCFlow_SR_model.py:33-36, then :118): the one-launch Adam re-points
+        # the parameters into its flat buffer underneath DDP; two steps, the loss moves, gradients keep arriving in DDP's buckets
+        from hcflow_amd import optim as hopt
+        opt = hopt.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-5, betas=(0.9, 0.99))
+        losses = []
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            _, l = ddp(hr=hr, lr=lr, reverse=False, noise=noise)
+            l.backward()
+            hopt.clip_grad_norm_(net.parameters(), 100.0)
+            opt.step()
+            losses.append(float(l.detach()))
+        assert abs(losses[0] - float(nll.detach())) <= 1e-6 * max(1.0, abs(losses[0]))
+        assert len(set(losses)) == 3 and all(l_ == l_ for l_ in losses)
+        assert len({p.untyped_storage().data_ptr() for p in net.parameters() if p.requires_grad}) == 1
     finally:
         dist.destroy_process_group()
 
