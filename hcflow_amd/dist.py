@@ -97,15 +97,33 @@ def sharded_rescale_roundtrip(net, hr: torch.Tensor, eps_std: float = 1.0, group
 
 
 # ---------------------------------------------------------------- the benchmark's N-GPU step (bench.py --gpus N)
-def gathered_step(net, lr: torch.Tensor, tau: float, seed: int, out_all: Optional[torch.Tensor] = None, group=None, **kw):
+_pending = []        # (Work, input tensor) of the overlapped all-gathers still in flight
+
+
+def gather_flush():
+    """Wait for the overlapped all-gathers of gathered_step (RCCL: the current stream waits for the collective's stream)."""
+    while _pending:
+        w, _keep = _pending.pop(0)
+        w.wait()
+
+
+def gathered_step(net, lr: torch.Tensor, tau: float, seed: int, out_all: Optional[torch.Tensor] = None, group=None,
+                  overlap: bool = True, **kw):
     """One bench step on this rank: sample THIS rank's shard (its LR batch; eps of global samples [rank B, (rank + 1) B) of the
     job-wide seed, hcf_inverse_ex) and, for N > 1, all-gather the output batch into ``out_all`` -- the only collective of the
-    path (RCCL over xGMI with backend "nccl"). Weak scaling: per-rank work is fixed."""
+    path (RCCL over xGMI with backend "nccl"). Weak scaling: per-rank work is fixed.
+    ``overlap``: the all-gather is issued asynchronously on the collective's own stream behind this step's kernels and the NEXT
+    step's sampling runs beside it (78.6 MB per rank and step at the bench size: 7 x that arrives per GPU at N = 8); the
+    previous step's gather is waited for before ``out_all`` is written again, and timed_region / gather_flush() wait for the last."""
     on = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
     out = net(lr=lr, z=None, u=None, eps_std=tau, reverse=True, seed=seed, sample_offset=rank * lr.shape[0], **kw)
     if out_all is not None and on and dist.get_world_size(group) > 1:
-        dist.all_gather_into_tensor(out_all, out.contiguous(), group=group)
+        gather_flush()
+        src = out.contiguous()
+        w = dist.all_gather_into_tensor(out_all, src, group=group, async_op=bool(overlap))
+        if overlap:
+            _pending.append((w, src))
     return out
 
 
@@ -122,6 +140,7 @@ def timed_region(step_fn: Callable[[int], object], steps: int, first: int = 0, g
     t0 = time.perf_counter()
     for i in range(steps):
         step_fn(first + i)
+    gather_flush()                                   # overlapped all-gathers of the last step: inside the timed window
     if on:
         dist.barrier(group=group)
     if cuda:
