@@ -19,6 +19,7 @@ aligned slots) when the optimiser is built, so ``nn.Parameter`` identities, shap
 (the drop-in nets re-bind their engine to the new addresses on the next call). Parameters must already be on the GPU (build the
 optimiser after ``.to(device)``, as the reference does): there is no CPU path.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -57,8 +58,9 @@ class _Flat:
             self.adopt(p, off, n)
         self.pptr = [self.P.data_ptr() + 4 * off for off in offs]
         self.t = np.zeros(len(params), np.int64)         # Adam's step count per parameter (torch keeps state['step'] per tensor)
-        self.key = None                                  # gradient pointers the chunk tables were built for
-        self.tables = []                                 # [(step count, device chunk table, n_chunks, keep-alive)]
+        self.key = None                                  # gradient pointers the current chunk tables were built for
+        self.tables = []                                 # [(a member tensor's index, device chunk table, n_chunks, keep-alive)]
+        self.recent = collections.OrderedDict()          # the last few (pointers -> tables); valid while the step-count classes stand
 
     def adopt(self, p, off, n):
         with torch.no_grad():
@@ -163,6 +165,7 @@ class Adam(torch.optim.Optimizer):
                     fl.t[i] = int(round(float(st["step"])))
                     self.state[p] = {"exp_avg": m, "exp_avg_sq": v}
                 fl.key = None
+                fl.recent.clear()
 
     # ---- the step ---------------------------------------------------------------------------------------------------------
     def _tables(self, fl, params, ptrs, active):
@@ -191,7 +194,7 @@ class Adam(torch.optim.Optimizer):
             tab["n"] = np.minimum(_CHUNK, n[seg] - _CHUNK * k).astype(np.uint32)
             host = torch.from_numpy(tab.view(np.uint8).reshape(-1)).pin_memory()
             dev = host.to(fl.device, non_blocking=True)
-            tables.append((int(t), dev, len(seg), host))
+            tables.append((int(act[sel][0]), dev, len(seg), host))
         return tables
 
     @torch.no_grad()
@@ -218,25 +221,32 @@ class Adam(torch.optim.Optimizer):
                 if p not in state:                              # first gradient, or the scheduler cleared the state on a restart
                     self._init_state(fl, i, p)
                     fl.key = None
+                    fl.recent.clear()
             if not active:
                 continue
             key = tuple(ptrs)
             if fl.key != key:
-                fl.tables = self._tables(fl, params, ptrs, active)
-                fl.key = key
+                # (the caching allocator may hand the backward pass one of a few blocks in turn: the last few tables are kept
+                #  instead of rebuilding and re-uploading ~1 500 records whenever the gradient buffer alternates)
+                ta = fl.t[np.asarray(active, np.int64)]
+                sig = (ta - ta[0]).tobytes()                    # which tensors share a step count (a table is per count)
+                hit = fl.recent.get(key)
+                if hit is None or hit[0] != sig:
+                    hit = (sig, self._tables(fl, params, ptrs, active))
+                    fl.recent[key] = hit
+                    if len(fl.recent) > 4:
+                        fl.recent.popitem(last=False)
+                fl.tables, fl.key = hit[1], key
             beta1, beta2 = group["betas"]
             stream = torch.cuda.current_stream(fl.device).cuda_stream
             with torch.cuda.device(fl.device):
-                for (t, dev, n, _keep) in fl.tables:
+                for (first, dev, n, _keep) in fl.tables:          # one table per step count (`first`: a member tensor of it)
                     rc = self._lib.hcf_adam_step(fl.P.data_ptr(), fl.M.data_ptr(), fl.V.data_ptr(), dev.data_ptr(), n,
                                                  float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                                                 float(group["weight_decay"]), t + 1, C.c_void_p(stream))
+                                                 float(group["weight_decay"]), int(fl.t[first]) + 1, C.c_void_p(stream))
                     if rc != 0:
                         raise _lib.HcfError("hcf_adam_step failed (%d)" % rc)
-            if len(fl.tables) > 1:
-                fl.key = None                                   # mixed step counts: tables are per count, rebuild next time
             fl.t[active] += 1
-            fl.tables = [(t + 1, dev, n, keep) for (t, dev, n, keep) in fl.tables]
             # the kernel wrote through raw pointers: tell autograd (and the nets' engines, which watch _version) the tensors changed
             torch.autograd.graph.increment_version([params[i] for i in active])
         return loss

@@ -224,3 +224,29 @@ def test_optimizer_survives_a_copy_and_refuses_moved_parameters():
     a[3].grad = torch.ones_like(a[3])
     with pytest.raises(_lib.HcfError):
         mine.step()
+
+
+def test_alternating_gradient_buffers_and_late_tensors_reuse_the_right_tables():
+    """The chunk tables are cached per gradient-pointer set: two flat buffers taken in turn, with one tensor skipping a step in
+    between (its step count falls behind: another table layout for the same pointers), still equal torch.optim.Adam."""
+    from hcflow_amd import optim
+    a, b = _twins(6)
+    mine = optim.Adam(a, lr=1e-3, betas=(0.9, 0.99))
+    ref = torch.optim.Adam(b, lr=1e-3, betas=(0.9, 0.99))
+    total = sum(p.numel() for p in a)
+    bufs = [torch.empty(total + 1, device="cuda") for _ in range(2)]
+    g = torch.Generator().manual_seed(800)
+    for it in range(8):
+        buf = bufs[it & 1]
+        buf.copy_((torch.randn(total + 1, generator=g) * 2).cuda())
+        off = 1
+        for i, (p, q) in enumerate(zip(a, b)):
+            n = p.numel()
+            skip = (it == 3 and i == 4)
+            p.grad = None if skip else buf[off:off + n].view(p.shape)
+            q.grad = None if skip else buf[off:off + n].view(p.shape).clone()
+            off += n
+        mine.step(); ref.step()
+    for p, q in zip(a, b):
+        _close(p, q)
+    assert float(mine.state_dict()["state"][4]["step"]) == 7.0
