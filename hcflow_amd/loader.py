@@ -82,7 +82,9 @@ def evaluate_batch(net, batch: Dict, heats: Iterable[float], n_sample: int, scal
             lp = [0.0] * B
             for s in range(n_sample):
                 kw = {} if seed is None else {"seed": seed + 1000 * hi + s}
-                sr = net(lr=lq, z=None, u=None, eps_std=heat, reverse=True, training=False, **kw)
+                # every heat / sample of the sweep conditions on the SAME lq: the deepest level's conditional features (the RRDB
+                # trunk: most of a Face x8 call) are computed once and reused, bit-identical outputs (arch.py: cache_cond)
+                sr = net(lr=lq, z=None, u=None, eps_std=heat, reverse=True, training=False, cache_cond=True, **kw)
                 samples.append(sr)
                 if gt is not None:
                     for b, m in enumerate(M.psnr_ssim(gt, sr, crop, scale)):
