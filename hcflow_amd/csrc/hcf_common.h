@@ -83,8 +83,9 @@ struct ConvArgs {
   // image fills 40 of 64 tile columns, the strip 640 of 656). strip_magic = 2^32 / strip_w + 1 (exact division of < 2^16).
   int strip_w; unsigned strip_magic;
 };
-// grid of the scaled f16x3 variant for a [B, H, W] tensor (= rows of ConvArgs::fb_part), strips included
-int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w = nullptr);
+// grid of the scaled f16x3 variant for a [B, H, W] tensor (= rows of ConvArgs::fb_part when tile_h is asked for), strips and the
+// 4-row tiles of small grids included
+int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w = nullptr, int* tile_h = nullptr);
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
 // Branch-free activation for unrolled epilogues: a runtime `if (act == ...)` chain per accumulator compiles to a chain of

@@ -76,15 +76,26 @@ int g_f16x3_ablation = 0;   // tools/conv_bench.py --ablate N (bit0/bit1 toggle 
 // a dx-major sliding-window tap loop (fewer LDS reads, same time), a pre-split activation format with register staging,
 // persistent blocks with the next tile's first chunk prefetched (VGPR cap: spills), a first-round block stagger.
 
-int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w) {
-  const int tiles_y = (H + 7) / 8, per_image = B * ((W + 31) / 32) * tiles_y;
+int conv_f16x3_scaled_blocks(int B, int H, int W, int* strip_w, int* tile_h) {
+  int tiles_y = (H + 7) / 8;
+  const int per_row = B * ((W + 31) / 32);
+  int row_tiles = per_row;
   if (strip_w) *strip_w = 0;
+  if (tile_h) *tile_h = 8;
   const bool off = getenv("HCF_NO_DG_STRIP") != nullptr;             // A/B knob
-  if (off || B < 2 || (long long)B * (W + 1) >= 65536) return per_image;
-  const int strips = ((B * (W + 1) + 31) / 32) * tiles_y;
-  if (strips * 10 > per_image * 9) return per_image;
-  if (strip_w) *strip_w = W + 1;
-  return strips;
+  if (!off && B >= 2 && (long long)B * (W + 1) < 65536) {
+    const int strips = (B * (W + 1) + 31) / 32;
+    if (strips * 10 <= per_row * 9) {
+      row_tiles = strips;
+      if (strip_w) *strip_w = W + 1;
+    }
+  }
+  // 4-row tiles while even they leave the grid within one block per CU (HCF_NO_DG_TH4: A/B knob)
+  if (tile_h && getenv("HCF_NO_DG_TH4") == nullptr && (long long)row_tiles * ((H + 3) / 4) <= 256) {
+    *tile_h = 4;
+    tiles_y = (H + 3) / 4;
+  }
+  return row_tiles * tiles_y;
 }
 
 namespace f16x3 {
@@ -121,11 +132,15 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // (a.in_max, device) before the split and the accumulators are scaled back in the epilogue: gradients of 1e-8 would
 // otherwise fall below the f16 split's absolute floor (a_lo is unscaled).
 template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false>
-__global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
   static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
   static_assert(TH == 8 || (!FUSE2 && TAILC == 0), "fused epilogues are sized for the 8-row tile");
-  constexpr int NTHR = 32 * TH;
+  static_assert(TH == 4 || TH == 8 || TH == 16, "tile heights");
+  // TH = 4 (small grids, training sizes): the same four waves on HALF the rows each -- half the MFMAs per block on twice as many
+  // blocks. A grid of at most one block per CU is bound by its blocks' MFMA streams (profiles/r04_notes.md), so the launch is as
+  // long as ONE block: 4-row tiles when the 8-row grid would leave half of the CUs idle anyway.
+  constexpr int NTHR = (TH == 4) ? 256 : 32 * TH;
   // Interleaving the next chunk's split into the last taps is worth ~10 % on the plain kernels. The fused-tail
   // variants keep it off: they are a handful of small launches, and the extra live registers make the 24-channel
   // variant spill. (The wrong pixels once blamed on this combination came from the tail's matrix being read with
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   constexpr int NLOAD = HP * (KC / 4);
   constexpr int NSLOT = (NLOAD + NTHR - 1) / NTHR;   // float4 staging slots per thread (A)
   constexpr int NPAD = NTB * 32;
-  constexpr int MT = 2 * NTB;                       // 32-pixel row tiles per wave
+  constexpr int MT = (TH == 4) ? NTB : 2 * NTB;     // 32-pixel row tiles per wave
   constexpr int A_BYTES = HP * REC;
   constexpr int BHALF = NPAD * 16;                  // bytes of one (tap, plane, k-half): n x 8 halves
   constexpr int B_BYTES = TAPS * 2 * 2 * BHALF;     // per chunk
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   constexpr int HCS = (NTB == 1) ? 33 : 49;                      // odd row stride of the h tile (floats): conflict-free
   constexpr int T_BYTES = TAILC ? (TH * TW) * HCS * 4 : 0;
   constexpr int LDS_MAIN = A_BYTES + B_BYTES;
-  constexpr int E_BYTES = (TH == 8 && TAILC == 0) ? TH * TW * NPAD * 4 : 0;     // fp32 output tile, transposed for 16-byte stores
+  constexpr int E_BYTES = (TH <= 8 && TAILC == 0) ? TH * TW * NPAD * 4 : 0;     // fp32 output tile, transposed for 16-byte stores
   constexpr int LDS_M1 = (LDS_MAIN > F2_BYTES ? (LDS_MAIN > T_BYTES ? LDS_MAIN : T_BYTES) : (F2_BYTES > T_BYTES ? F2_BYTES : T_BYTES));
   constexpr int LDS_BYTES = LDS_M1 > E_BYTES ? LDS_M1 : E_BYTES;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB 
   const float bias = FUSE2 ? a.bias2[oc] : a.bias[oc], scale = FUSE2 ? a.scale2[oc] : a.scale[oc];
   const float slope = act_slope(FUSE2 ? a.act2 : a.act);
   bool done_vec = false;
-  if constexpr (TH == 8) {
+  if constexpr (TH <= 8) {
     if (a.vec_epi) {
       // The tile goes through LDS (pixel-major fp32) so that every lane loads its residuals and stores its outputs as
       // 16 contiguous bytes: 64 scalar dword stores per lane cost ~12 us per block on the 64-channel tile (measured in
@@ -681,10 +696,13 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   else if (tall)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, false, true, false, 0, 16>), dim3((unsigned)nblk), dim3(512), 0, st, b);
   else if (a.in_max && vec && !b.any_up) {
+    int th = 8;
     if (b.vec_epi) {                               // strips on narrow images (the vector epilogue maps pixels back per image)
-      nblk = conv_f16x3_scaled_blocks(a.B, a.H, a.W, &b.strip_w);
+      nblk = conv_f16x3_scaled_blocks(a.B, a.H, a.W, &b.strip_w, &th);
       b.strip_magic = b.strip_w ? (unsigned)(0x100000000ull / (unsigned)b.strip_w) + 1u : 0u;
     }
+    if (th == 4) hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 4, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    else
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   }
   else if (a.in_max)

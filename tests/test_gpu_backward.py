@@ -73,7 +73,8 @@ def test_conv2d_weight_gradient_f16x3_strips(shape, monkeypatch):
     try:
         res = []
         for off in (False, False, True):
-            for k in ("HCF_NO_WG_STRIP", "HCF_NO_DG_STRIP"):      # the scaled data-gradient conv walks strips as well
+            for k in ("HCF_NO_WG_STRIP", "HCF_NO_DG_STRIP", "HCF_NO_DG_TH4"):      # the scaled data-gradient conv walks strips as well,
+                # and takes 4-row tiles while the grid stays within one block per CU
                 if off:
                     monkeypatch.setenv(k, "1")
                 else:
