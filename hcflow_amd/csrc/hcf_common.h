@@ -143,6 +143,9 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a, int* nblk_x = nullptr, int*
 // step: ~630 reduce launches of ~7 us become ~40). Same summation order per dW element as the stand-alone reduce.
 struct WgradReduceJob { WgradArgs a; int nx, nicb, nocb, nbx; long long blk0; };
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t st, WgradReduceJob* defer = nullptr);
+constexpr int kWgBatchMax = 5;
+struct WgradBatchArgs { WgradArgs a[kWgBatchMax]; int blk0[kWgBatchMax + 1], nicb[kWgBatchMax], nocb[kWgBatchMax], n; };   // kernel argument
+int launch_conv_wgrad_batch(const WgradArgs* jobs, int n, hipStream_t st, WgradReduceJob* defer);
 int launch_wgrad_reduce_batch(const WgradReduceJob* jobs_dev, int njobs, long long nblocks, hipStream_t st);
 int launch_absmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |g| (out zero-initialised)
 int launch_wino_vmax(const View& g, int B, int H, int W, float* out, hipStream_t st);   // *out = max |B^T d B| over the F(2x2,3x3) patches

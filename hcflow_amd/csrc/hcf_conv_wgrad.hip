@@ -16,6 +16,7 @@
 //            (deterministic; the first version used fp32 atomics and spent 10-25x the MFMA time in them).
 #include "hcf_common.h"
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 
 namespace hcf {
@@ -243,8 +244,10 @@ template <int TAPS> struct Wg16 {
   static constexpr int LDS_BYTES = 2 * XB + 3 * GB;              // 92 672 (3x3) / 81 920 (1x1): X hi, lo'; G hi, lo, hi * 2^-11
 };
 
+// (bxi, byi, bzi) = (pixel slice, input-channel block, output-channel block) in a grid of (., gdy, gdz): the block coordinates of
+// the one-conv launch, or decoded from a linear block number by the batched launch
 template <int TAPS, bool VEC>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int bxi, const int byi, const int bzi, const int gdy, const int gdz) {
   typedef Wg16<TAPS> C;
   constexpr int PAD = C::PAD, HW = C::HW, HP = C::HP, XB = C::XB, GB = C::GB;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
   const int tiles_x = sw ? (svw + TW - 1) / TW : (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = sw ? tiles_x * tiles_y : a.B * tiles_x * tiles_y;
 
-  int blk = blockIdx.y, si = 0;
+  int blk = byi, si = 0;
   for (; si < a.nsrc; ++si) {
     const int nb = (a.src[si].n + 31) >> 5;
     if (blk < nb) break;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
   const View sv = a.src[si];
   const int ic0 = blk * 32;
   const int icn = min(32, sv.n - ic0);
-  const int oc0 = blockIdx.z * 32;
+  const int oc0 = bzi * 32;
   const int ocn = min(32, a.g.n - oc0);
   const int up = sv.up, Hs = H >> up, Ws = W >> up;
 
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
   const char* const xw = xh + lofs + wave * (HW * 64);           // this wave's image row (row + dy through immediates)
   const char* const gw = gh + lofs + wave * (TW * 64);
 
-  const int t0 = blockIdx.x * a.tpb, t1 = min(ntiles, t0 + a.tpb);
+  const int t0 = bxi * a.tpb, t1 = min(ntiles, t0 + a.tpb);
   if (t0 < t1) HCF_WG_LOAD(t0)
   for (int tile = t0; tile < t1; ++tile) {
     __syncthreads();                              // the previous tile's fragments have been read
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
   __syncthreads();
 #undef HCF_WG_ROUND
   if (wave != 0) return;
-  float* part = a.part + ((size_t)((size_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (TAPS * 1024);
+  float* part = a.part + ((size_t)((size_t)bxi * gdy + byi) * gdz + bzi) * (TAPS * 1024);
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -439,6 +442,27 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArg
       const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       part[t * 1024 + m * 32 + (lane & 31)] = (acc[t][r] + red[(t * 16 + r) * 64 + lane]) * g_inv;
     }
+}
+
+
+template <int TAPS, bool VEC>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArgs a) {
+  wgrad_f16x3_body<TAPS, VEC>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gridDim.z);
+}
+
+// Several convs' weight gradients as ONE launch (the five convs of a dense block: hcf_engine_train.inc). A one-conv launch is at
+// most one round of one-per-CU blocks, i.e. 2-3 tiles per block behind a 13 us fixed part (prologue + the eight-wave reduce tree);
+// here the same block budget covers all the convs, every block walks 10+ tiles, and the fixed part is paid once per block instead
+// of once per conv and block: 234 blocks x 68 us for a dense block at 16 x 40 x 40 against 5 x (160 blocks x 22-27 us).
+template <bool VEC>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_batch_kernel(const WgradBatchArgs b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;      // block-uniform
+  int r = (int)blockIdx.x - b.blk0[j];
+  const int nicb = b.nicb[j], nocb = b.nocb[j];
+  const int bz = r % nocb; r /= nocb;
+  const int by = r % nicb; r /= nicb;
+  wgrad_f16x3_body<9, VEC>(b.a[j], r, by, bz, nicb, nocb);
 }
 
 // dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
@@ -651,6 +675,56 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer
   }
   const dim3 rgrid((unsigned)((a.taps * 1024 + 255) / 256), (unsigned)nicb, (unsigned)nocb);
   hipLaunchKernelGGL(wgrad::wgrad_reduce_kernel, rgrid, dim3(256), 0, st, a, nblk_x, a.taps);
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
+// f16x3 3x3 weight gradients of n <= kWgBatchMax convs as one launch; jobs[i].part / part_cap / blocks_hint set by the caller
+// (conv_wgrad_scratch_floats with the same blocks_hint sizes part). HCF_ERR_UNSUPPORTED: some job does not qualify (no g_max,
+// 1x1, unaligned views) -- the caller launches them one by one. defer[i] receives job i's reduce step.
+int launch_conv_wgrad_batch(const WgradArgs* jobs, int n, hipStream_t st, WgradReduceJob* defer) {
+  if (!jobs || n < 1 || n > kWgBatchMax || !defer) return HCF_ERR_ARG;
+  WgradBatchArgs b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    WgradArgs a = jobs[i];
+    if (a.nsrc < 1 || a.nsrc > kMaxSrc || !a.dw || !a.g.p || a.g.n < 1 || !a.part) return HCF_ERR_ARG;
+    if (a.taps != 9 || !a.g_max) return HCF_ERR_UNSUPPORTED;
+    int nicb = 0, cin = 0;
+    bool vec = (((a.g.cs | a.g.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.g.p) & 15) == 0);
+    for (int k = 0; k < a.nsrc; ++k) {
+      if ((a.H >> a.src[k].up) << a.src[k].up != a.H || (a.W >> a.src[k].up) << a.src[k].up != a.W) return HCF_ERR_ARG;
+      nicb += (a.src[k].n + 31) >> 5;
+      cin += a.src[k].n;
+      vec = vec && (((a.src[k].cs | a.src[k].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[k].p) & 15) == 0);
+    }
+    if (!vec) return HCF_ERR_UNSUPPORTED;
+    a.cin_total = cin;
+    a.dbg = 0;
+    int nblk_x = 0;
+    const size_t need = conv_wgrad_scratch_floats(a, &nblk_x, &a.tpb);
+    if (need > a.part_cap) return HCF_ERR_NOMEM;
+    (void)wgrad_tiles(a, &a.strip_w);
+    a.strip_magic = a.strip_w ? (unsigned)(0x100000000ull / (unsigned)a.strip_w) + 1u : 0u;
+    const int nocb = (a.g.n + 31) >> 5;
+    b.a[i] = a;
+    b.nicb[i] = nicb; b.nocb[i] = nocb;
+    b.blk0[i] = total;
+    total += nblk_x * nicb * nocb;
+    defer[i].a = a; defer[i].nx = nblk_x; defer[i].nicb = nicb; defer[i].nocb = nocb; defer[i].nbx = (9 * 1024 + 255) / 256; defer[i].blk0 = 0;
+  }
+  b.blk0[n] = total;
+  static bool attr_dev[64] = {};
+  int dev_ = 0;
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
+  auto fn = wgrad::conv_wgrad_f16x3_batch_kernel<true>;
+  if (!attr_dev[dev_]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, wgrad::Wg16<9>::LDS_BYTES) != hipSuccess)
+      return HCF_ERR_HIP;
+    attr_dev[dev_] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(512), wgrad::Wg16<9>::LDS_BYTES, st, b);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
