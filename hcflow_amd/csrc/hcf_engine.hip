@@ -1559,6 +1559,9 @@ void hcf_destroy(hcf_engine* e) {
   if (e->wg_stream) { hipStreamSynchronize(e->wg_stream); hipStreamDestroy(e->wg_stream); }
   if (e->wg_ev) hipEventDestroy(e->wg_ev);
   if (e->wg_done) hipEventDestroy(e->wg_done);
+  if (e->dg_stream) { hipStreamSynchronize(e->dg_stream); hipStreamDestroy(e->dg_stream); }
+  if (e->dg_ev) hipEventDestroy(e->dg_ev);
+  if (e->dg_done) hipEventDestroy(e->dg_done);
   if (e->axpy_jobs_dev) hipFree(e->axpy_jobs_dev);
   if (e->sum_jobs_dev) hipFree(e->sum_jobs_dev);
   if (e->rt.blob) hipFree(e->rt.blob);
