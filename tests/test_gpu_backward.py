@@ -615,3 +615,45 @@ def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(
             ndiff += int(not np.array_equal(a, b))
             assert float(np.abs(a - b).max()) <= 2e-6 * max(float(np.abs(b).max()), 1e-30)
     assert ndiff > 0                                      # the knob did select another summation order
+
+
+def test_training_step_on_a_side_stream_equals_the_default_stream():
+    """The backward pass spreads over the caller's stream and the engine's own streams (weight gradients; the data gradients into the
+    conditional features), tied together by events on whatever stream the caller is on: a step inside torch.cuda.stream(side) gives
+    the gradients of the default-stream step bit for bit, with the optimiser's kernels queued right behind it on the same stream."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR, optim
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, spec_grads
+    cfg = preset("SR_4X_tiny")
+    g = torch.Generator().manual_seed(41)
+    hr = torch.rand(2, 3, 64, 96, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    res = []
+    for use_side in (False, True):
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(cached_params("SR_4X_tiny", 11), strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to("cuda:0").train()
+        opt = optim.Adam([q for q in net.parameters() if q.requires_grad], lr=1e-6)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side) if use_side else torch.cuda.stream(torch.cuda.current_stream())
+        steps = []
+        with ctx:
+            for it in range(2):
+                opt.zero_grad(set_to_none=True)
+                _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+                nll.backward()
+                grads = spec_grads(net, cfg)
+                opt.step()
+                steps.append((float(nll.detach()), grads))
+        torch.cuda.synchronize()
+        res.append(steps)
+    for (n0, g0), (n1, g1) in zip(res[0], res[1]):
+        assert n0 == n1
+        for a, b in zip(g0, g1):
+            assert np.array_equal(a, b)
