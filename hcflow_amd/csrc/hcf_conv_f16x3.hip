@@ -707,8 +707,14 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   }
   else if (a.in_max)
     return HCF_ERR_UNSUPPORTED;
-  else if (vec && !b.any_up)
+  else if (vec && !b.any_up) {
+    // small grids: 4-row tiles while even they stay within one block per CU (bit-identical to the 8-row form; HCF_NO_TH4: A/B knob)
+    const long long nblk4 = (long long)a.B * tiles_x * ((a.H + 3) / 4);
+    if (b.vec_epi && nblk4 <= 256 && getenv("HCF_NO_TH4") == nullptr)
+      hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+    else
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  }
   else if (vec)
     hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
   else
