@@ -135,7 +135,7 @@ template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH 
 __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
   static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
-  static_assert(TH == 8 || (!FUSE2 && TAILC == 0), "fused epilogues are sized for the 8-row tile");
+  static_assert(TH == 8 || TH == 4 || (!FUSE2 && TAILC == 0), "the fused epilogues are sized for the 8- and 4-row tiles");
   static_assert(TH == 4 || TH == 8 || TH == 16, "tile heights");
   // TH = 4 (small grids, training sizes): the same four waves on HALF the rows each -- half the MFMAs per block on twice as many
   // blocks. A grid of at most one block per CU is bound by its blocks' MFMA streams (profiles/r04_notes.md), so the launch is as
@@ -496,7 +496,7 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
     const int y = y0 + ty, x = x0 + tx;
-    if (y < H && x < W) {
+    if (ty < TH && y < H && x < W) {                  // (4-row tiles: the upper half of the block's threads has no pixel)
       const size_t pix = (size_t)((size_t)b * H + y) * W + x;
       float z[TAILC], yv[TAILC];
       load_pixel<TAILC>(a.tz, pix, a.tC, z);
@@ -672,6 +672,12 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     if (!vec || b.any_up || a.w2 || a.res1.p || a.res2.p || a.act != ACT_NONE || a.out.n > ((NTB == 1) ? 32 : 48)) return HCF_ERR_ARG;
     const int cm = step_cmax(a.tC);
     if constexpr (NTB == 1) {
+      const long long nblk4 = (long long)a.B * tiles_x * ((a.H + 3) / 4);
+      const bool th4 = nblk4 <= 256 && getenv("HCF_NO_TH4") == nullptr;      // small grids: 4-row tiles (see the plain variant below)
+      if (th4 && cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+      else if (th4 && cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+      else if (th4 && cm == 24) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 24, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+      else
       if (cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8>), dim3((unsigned)nblk), dim3(256), 0, st, b);
       else if (cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12>), dim3((unsigned)nblk), dim3(256), 0, st, b);
       else if (cm == 24) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 24>), dim3((unsigned)nblk), dim3(256), 0, st, b);
@@ -682,8 +688,11 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   } else if (a.w2) {      // fused FCN conv1 + conv2
     if constexpr (NTB == 2) {
       if (!vec || a.out.n != 64 || !a.bias2 || !a.scale2 || a.res1.p || a.res2.p) return HCF_ERR_ARG;
+      const long long nblk4 = (long long)a.B * tiles_x * ((a.H + 3) / 4);
       if (b.any_up)
         hipLaunchKernelGGL((conv_f16x3_kernel<2, true, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else if (b.vec_epi && nblk4 <= 256 && getenv("HCF_NO_TH4") == nullptr)      // small grids: 4-row tiles
+        hipLaunchKernelGGL((conv_f16x3_kernel<2, true, false, true, 0, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
       else
         hipLaunchKernelGGL((conv_f16x3_kernel<2, true, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
     } else {
