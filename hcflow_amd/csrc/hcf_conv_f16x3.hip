@@ -131,7 +131,8 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // SCALED (training, data-gradient convs): the input tensor is multiplied by a power of two derived from its max |x|
 // (a.in_max, device) before the split and the accumulators are scaled back in the epilogue: gradients of 1e-8 would
 // otherwise fall below the f16 split's absolute floor (a_lo is unscaled).
-template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false>
+// K1 (training: the FCNs' stand-alone 1x1 conv2 and its data gradient; the inference passes run it fused, FUSE2): one tap, no halo.
+template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false, bool K1 = false>
 __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
   static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
@@ -145,9 +146,10 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
   // variants keep it off: they are a handful of small launches, and the extra live registers make the 24-channel
   // variant spill. (The wrong pixels once blamed on this combination came from the tail's matrix being read with
   // uniform-address VECTOR loads, see hcf_step_math.h const_table(); tests/test_gpu_f16x3.py::test_large_grid_*.)
-  constexpr bool INTERLEAVE = (TAILC == 0);
+  constexpr bool INTERLEAVE = (TAILC == 0) && !K1;
+  static_assert(!K1 || (!FUSE2 && TAILC == 0 && !UP && TH <= 8), "the one-tap form is a plain / scaled variant");
   static_assert(!FUSE2 || NTB == 2, "the fused 1x1 layer needs all 64 channels of the tile in one block");
-  constexpr int TAPS = 9, PAD = 1;
+  constexpr int TAPS = K1 ? 1 : 9, PAD = K1 ? 0 : 1;
   constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   constexpr int NLOAD = HP * (KC / 4);
   constexpr int NSLOT = (NLOAD + NTHR - 1) / NTHR;   // float4 staging slots per thread (A)
@@ -731,6 +733,39 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
+// stand-alone 1x1 conv (training): 16-byte addressable windows, no upsample, vector epilogue; anything else stays on the exact kernel
+template <int NTB>
+static int launch_k1(const ConvArgs& a, hipStream_t st) {
+  if (a.tC > 0 || a.w2 || getenv("HCF_NO_K1") != nullptr) return HCF_ERR_UNSUPPORTED;      // HCF_NO_K1: 1x1 convs on the exact kernel (A/B)
+  ConvArgs b = a;
+  b.any_up = 0; b.strip_w = 0; b.strip_magic = 0;
+  auto v4 = [](const View& v) { return !v.p || ((((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0)); };
+  b.vec_epi = a.out.p && (a.out.n & 3) == 0 && v4(a.out) && v4(a.res1) && v4(a.res2);
+  if (!b.vec_epi) return HCF_ERR_UNSUPPORTED;
+  for (int i = 0; i < a.nsrc; ++i) {
+    if (a.src[i].up || ((a.src[i].cs | a.src[i].c0) & 3) || (reinterpret_cast<uintptr_t>(a.src[i].p) & 15)) return HCF_ERR_UNSUPPORTED;
+    if ((long long)a.B * a.H * a.W * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
+  }
+  if (a.fb_y.p) return HCF_ERR_UNSUPPORTED;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  long long nblk = (long long)a.B * tiles_x * ((a.H + 7) / 8);
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;
+  if (a.in_max) {
+    int th = 8;
+    nblk = conv_f16x3_scaled_blocks(a.B, a.H, a.W, &b.strip_w, &th);
+    b.strip_magic = b.strip_w ? (unsigned)(0x100000000ull / (unsigned)b.strip_w) + 1u : 0u;
+    if (th == 4) hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 4, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, true, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  } else {
+    const long long nblk4 = (long long)a.B * tiles_x * ((a.H + 3) / 4);
+    if (nblk4 <= 256 && getenv("HCF_NO_TH4") == nullptr)
+      hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 4, false, true>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+    else
+      hipLaunchKernelGGL((conv_f16x3_kernel<NTB, true, false, false, 0, 8, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+  }
+  return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
+}
+
 }  // namespace f16x3
 
 // a.wpack must point at the f16x3 pack (pack_conv_weights_f16x3), a.ovf at a device int
@@ -741,7 +776,9 @@ int launch_conv_f16x3(const ConvArgs& a, int taps, hipStream_t st) {
   const int nt = (a.out.n + 31) / 32;
   if (taps == 9 && nt == 1) return f16x3::launch_t<1>(a, st);
   if (taps == 9 && nt == 2) return f16x3::launch_t<2>(a, st);
-  // 1x1 convs (FCN conv2) and > 64 output channels stay on the exact kernel
+  if (taps == 1 && nt == 1) return f16x3::launch_k1<1>(a, st);
+  if (taps == 1 && nt == 2) return f16x3::launch_k1<2>(a, st);
+  // > 64 output channels stay on the exact kernel
   return HCF_ERR_UNSUPPORTED;
 }
 

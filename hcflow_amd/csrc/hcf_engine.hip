@@ -811,7 +811,7 @@ struct hcf_engine {
     }
     if (fat && r != HCF_OK) { fail(HCF_ERR_STATE, "internal: a fat dense-block launch did not take the Winograd kernel"); return; }
     if (r != HCF_ERR_UNSUPPORTED) {
-    } else if (use_f16 && cv.wpack16 && cv.taps == 9) {
+    } else if (use_f16 && cv.wpack16 && (cv.taps == 9 || (cv.taps == 1 && !fuse2 && !tail))) {      // (a stand-alone 1x1: the training passes)
       a.wpack = cv.wpack16;
       a.ovf = ovf_flag;
       a.zeros = reinterpret_cast<const float*>(ovf_flag) + 16;
@@ -830,6 +830,7 @@ struct hcf_engine {
         if (r == HCF_ERR_UNSUPPORTED && res1.p) { fail(HCF_ERR_STATE, "internal: pre-activation term without the fcn12 kernel"); return; }
       }
       if (r == HCF_ERR_UNSUPPORTED) r = launch_conv_f16x3(a, cv.taps, st);
+      if (r == HCF_ERR_UNSUPPORTED && cv.taps == 1) { a.wpack = cv.wpack; r = launch_conv(a, cv.taps, st); }      // views the one-tap form does not take
     } else {
       r = launch_conv(a, cv.taps, st);
     }
