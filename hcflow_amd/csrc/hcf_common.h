@@ -75,9 +75,11 @@ struct ConvArgs {
   // f16x3 kernel, training (gather-form data gradient of a dense block, hcf_engine_train.inc): this conv's output IS the complete
   // dL/dy of the conv that produced `fb_y`; its epilogue applies that conv's epilogue backward on the spot -- out = dL/dpre =
   // dL/dy * act'(y) (activation fb_act, no residuals, unit scale) -- and leaves what conv_epilogue_bwd_kernel would: per-block partial
-  // sums of dL/dpre per channel in fb_part ([grid blocks][2][n]; the second row stays zero), max |dL/dpre| in fb_max, and
+  // sums of dL/dpre per channel in fb_part ([grid blocks][2][n]; second row: sums of dz * y when fb_zy, else zero; with fb_scale dL/dpre =
+  // dz * scale[c], dz = dL/dy * act'(y), as conv_epilogue_bwd_kernel), max |dL/dpre| in fb_max, and
   // max(|dL/dpre|, *in_max) in fb_max2 (a slot OTHER than in_max, which every block of this launch reads: the running max moves on).
   View fb_y; int fb_act; float* fb_part; float* fb_max; float* fb_max2;
+  const float* fb_scale; int fb_zy;        // producer's per-channel scale (null: none) and whether the second partial row (sum of dz * y) is wanted
   // set by the f16x3 launcher (scaled training variant only): 0, or W + 1 -- the 8 x 32 tiles walk STRIPS, the B images of a tile
   // row side by side with one zero column between them, instead of every image's own ceil(W / 32) tiles (narrow images: a 40-wide
   // image fills 40 of 64 tile columns, the strip 640 of 656). strip_magic = 2^32 / strip_w + 1 (exact division of < 2^16).

@@ -534,7 +534,9 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
       const bool h1 = a.res1.p != nullptr, h2 = a.res2.p != nullptr;
       const bool fb = SCALED && a.fb_y.p != nullptr;        // fused epilogue backward of the conv whose dL/dy this is (ConvArgs::fb_y)
       const float fb_neg = a.fb_act == ACT_RELU ? 0.f : a.fb_act == ACT_LRELU ? 0.2f : 1.f;
-      f32x4 fb_sum = {0.f, 0.f, 0.f, 0.f};
+      f32x4 fb_sum = {0.f, 0.f, 0.f, 0.f}, fb_szy = {0.f, 0.f, 0.f, 0.f};
+      f32x4 fb_sc = {1.f, 1.f, 1.f, 1.f};            // (this thread's channel quad is the same in every iteration: NTHR % C4 == 0)
+      if (fb && a.fb_scale && (tid % C4) < n4) fb_sc = *reinterpret_cast<const f32x4*>(a.fb_scale + 4 * (tid % C4));
       float fb_mx = 0.f;
 #pragma unroll 2
       for (int k = 0; k < (TH * TW * C4) / NTHR; ++k) {
@@ -559,8 +561,10 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const bool pos = a.fb_act == ACT_RELU ? (yv[e] > 0.f) : (yv[e] >= 0.f);      // as conv_epilogue_bwd_kernel
-              v[e] = pos ? v[e] : v[e] * fb_neg;
+              const float dz = (a.fb_act == ACT_NONE || pos) ? v[e] : v[e] * fb_neg;
+              v[e] = dz * fb_sc[e];
               fb_sum[e] += v[e];
+              fb_szy[e] += dz * yv[e];
               fb_mx = fmaxf(fb_mx, fabsf(v[e]));
             }
           }
@@ -573,18 +577,19 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
         static_assert(NTHR % C4 == 0, "one channel quad per thread");
         __syncthreads();                               // the tile in LDS has been read
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ldsT[tid * 4 + e] = fb_sum[e];
-        int* const fb_shm = reinterpret_cast<int*>(ldsT + NTHR * 4);      // (a word of the tile buffer: no extra static LDS)
+        for (int e = 0; e < 4; ++e) { ldsT[tid * 4 + e] = fb_sum[e]; ldsT[NTHR * 4 + tid * 4 + e] = fb_szy[e]; }
+        int* const fb_shm = reinterpret_cast<int*>(ldsT + 2 * NTHR * 4);      // (a word of the tile buffer: no extra static LDS)
+        static_assert(LDS_BYTES >= (2 * NTHR * 4 + 1) * 4, "the partial sums fit in the LDS buffer");
         if (tid == 0) *fb_shm = 0;
         __syncthreads();
         if (fb_mx > 0.f && fb_mx == fb_mx) atomicMax(fb_shm, __builtin_bit_cast(int, fb_mx));
         const int n = a.out.n;
         if (tid < n) {
           const int q4 = tid >> 2, e = tid & 3;
-          float t0 = 0.f;
-          for (int j = 0; j < NTHR / C4; ++j) t0 += ldsT[(j * C4 + q4) * 4 + e];
+          float t0 = 0.f, t1 = 0.f;
+          for (int j = 0; j < NTHR / C4; ++j) { t0 += ldsT[(j * C4 + q4) * 4 + e]; t1 += ldsT[NTHR * 4 + (j * C4 + q4) * 4 + e]; }
           a.fb_part[((size_t)blockIdx.x * 2 + 0) * n + tid] = t0;
-          a.fb_part[((size_t)blockIdx.x * 2 + 1) * n + tid] = 0.f;
+          a.fb_part[((size_t)blockIdx.x * 2 + 1) * n + tid] = a.fb_zy ? t1 : 0.f;
         }
         __syncthreads();
         if (tid == 0) {
@@ -662,7 +667,8 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
   }
   if (a.fb_y.p) {      // fused epilogue backward: the scaled, vector-epilogue variant only, 16-byte addressable y, whole channel quads
     auto v4b = [](const View& v) { return (((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0); };
-    if (!a.in_max || a.fb_max2 == a.in_max || !b.vec_epi || !a.fb_part || !v4b(a.fb_y) || (a.out.n & 3) || a.out.n > 32 * NTB) return HCF_ERR_UNSUPPORTED;
+    if (!a.in_max || a.fb_max2 == a.in_max || !b.vec_epi || !a.fb_part || !v4b(a.fb_y) || (a.out.n & 3) || a.out.n > 32 * NTB ||
+        (a.fb_scale && (reinterpret_cast<uintptr_t>(a.fb_scale) & 15))) return HCF_ERR_UNSUPPORTED;
   }
   for (int i = 0; i < a.nsrc; ++i) {
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
@@ -746,7 +752,11 @@ static int launch_k1(const ConvArgs& a, hipStream_t st) {
     if (a.src[i].up || ((a.src[i].cs | a.src[i].c0) & 3) || (reinterpret_cast<uintptr_t>(a.src[i].p) & 15)) return HCF_ERR_UNSUPPORTED;
     if ((long long)a.B * a.H * a.W * a.src[i].cs >= 0x7fffffffLL) return HCF_ERR_UNSUPPORTED;
   }
-  if (a.fb_y.p) return HCF_ERR_UNSUPPORTED;
+  if (a.fb_y.p) {
+    auto v4b = [](const View& v) { return (((v.cs | v.c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0); };
+    if (!a.in_max || a.fb_max2 == a.in_max || !a.fb_part || !v4b(a.fb_y) || a.out.n > 32 * NTB ||
+        (a.fb_scale && (reinterpret_cast<uintptr_t>(a.fb_scale) & 15))) return HCF_ERR_UNSUPPORTED;
+  }
   const int tiles_x = (a.W + TW - 1) / TW;
   long long nblk = (long long)a.B * tiles_x * ((a.H + 7) / 8);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return HCF_ERR_ARG;

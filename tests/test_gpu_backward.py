@@ -575,8 +575,8 @@ def test_dense_block_gather_form_data_gradients_equal_the_per_conv_form(precisio
 def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(monkeypatch):
     """f16x3 training: the gather conv of x_m (m >= 1) applies the epilogue backward of the conv that produced x_m in its own
     epilogue (ConvArgs::fb_y, hcf_engine_train.inc rdb_fuse_ok). dL/dpre is the same fp32 product either way, so weight gradients
-    are equal bit for bit; bias gradients are sums over differently shaped blocks (rounding only). HCF_NO_EPI_FUSE=1 selects the
-    separate conv_epilogue_bwd launch, read at the start of each backward pass."""
+    are equal bit for bit; bias / ActNorm gradients are sums over differently shaped blocks (rounding only). HCF_NO_EPI_FUSE=1 selects
+    the separate conv_epilogue_bwd launch (HCF_NO_FCN_FUSE=1: in the FCN chains only), read at the start of each backward pass."""
     import numpy as np
     from hcflow_amd import HCFlowNet_SR
     from hcflow_amd.config import preset
@@ -594,10 +594,11 @@ def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(
     net = net.to("cuda:0").train().set_precision("f16x3")
     res = []
     for off in (False, True, False):
-        if off:
-            monkeypatch.setenv("HCF_NO_EPI_FUSE", "1")
-        else:
-            monkeypatch.delenv("HCF_NO_EPI_FUSE", raising=False)
+        for k in ("HCF_NO_EPI_FUSE", "HCF_NO_FCN_FUSE"):      # (the FCNs' conv2 / conv3 data gradients apply conv1's / conv2's likewise)
+            if off:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
         net.zero_grad(set_to_none=True)
         _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
         nll.backward()
@@ -609,9 +610,9 @@ def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(
     ndiff = 0
     for a, b in zip(g0, g1):
         assert np.isfinite(a).all()
-        if a.ndim >= 2:
+        if a.size != max(a.shape):                        # conv / invconv weights: products of the same dL/dpre
             assert np.array_equal(a, b)
-        else:
+        else:                                             # vectors (conv biases, ActNorm bias / logs as [1, C, 1, 1]): sums over other blocks
             ndiff += int(not np.array_equal(a, b))
             assert float(np.abs(a - b).max()) <= 2e-6 * max(float(np.abs(b).max()), 1e-30)
     assert ndiff > 0                                      # the knob did select another summation order
