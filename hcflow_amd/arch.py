@@ -511,11 +511,18 @@ class _EngineModule(nn.Module):
             ptrs = tuple(p.data_ptr() for _, p in named)
             on_dev = all(p.device.type == "cuda" and p.device.index == idx and p.dtype == torch.float32 and p.is_contiguous()
                          for _, p in named)
-            if on_dev and ent.get("ptrs") == ptrs:
+            # The device-side refresh re-reads every PARAMETER; the LU-decomposed invertible convs' fixed buffers (p, sign_s:
+            # Permutations.py:54-55) are captured by hcf_finalize only. A load_state_dict / in-place write that changes them
+            # (a checkpoint's pivoting differs from the random init's) takes the full host path below.
+            lu_stamp = tuple((p.data_ptr(), p._version) for key, p in named
+                             if key.endswith(".permute.p") or key.endswith(".permute.sign_s"))
+            lu_same = ent.get("lu_stamp") == lu_stamp
+            ent["lu_stamp"] = lu_stamp
+            if on_dev and lu_same and ent.get("ptrs") == ptrs:
                 # same tensors, new contents (optimiser step): rewrite the packs on the device
                 with torch.cuda.device(idx):
                     eng.refresh_from_device(self._stream(idx))
-            elif on_dev and ent.get("ptrs") is not None:
+            elif on_dev and lu_same and ent.get("ptrs") is not None:
                 # other tensors of the same shapes (nn.DataParallel replicas are re-created every forward,
                 # HCFlow_SR_model.py:33-36 in the non-distributed case): re-bind and refresh on the device
                 with torch.cuda.device(idx):

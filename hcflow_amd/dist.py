@@ -108,11 +108,11 @@ def gather_flush():
 
 
 def gathered_step(net, lr: torch.Tensor, tau: float, seed: int, out_all: Optional[torch.Tensor] = None, group=None,
-                  overlap: bool = True, **kw):
+                  overlap: bool = False, **kw):
     """One bench step on this rank: sample THIS rank's shard (its LR batch; eps of global samples [rank B, (rank + 1) B) of the
     job-wide seed, hcf_inverse_ex) and, for N > 1, all-gather the output batch into ``out_all`` -- the only collective of the
     path (RCCL over xGMI with backend "nccl"). Weak scaling: per-rank work is fixed.
-    ``overlap``: the all-gather is issued asynchronously on the collective's own stream behind this step's kernels and the NEXT
+    ``overlap`` (default False: ``out_all`` is complete when the call returns; bench.py opts in): the all-gather is issued asynchronously on the collective's own stream behind this step's kernels and the NEXT
     step's sampling runs beside it (78.6 MB per rank and step at the bench size: 7 x that arrives per GPU at N = 8); the
     previous step's gather is waited for before ``out_all`` is written again, and timed_region / gather_flush() wait for the last."""
     on = dist.is_available() and dist.is_initialized()

@@ -75,9 +75,16 @@ class _Flat:
 class Adam(torch.optim.Optimizer):
     """``torch.optim.Adam`` (amsgrad=False, maximize=False) as one launch per parameter group and step."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, foreach=None,
+                 maximize=False, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False):
         if amsgrad:
             raise ValueError("hcflow_amd.optim.Adam: amsgrad is not implemented (the reference never sets it)")
+        # torch.optim.Adam's keyword-only arguments are accepted at their defaults (foreach / fused only choose torch's own
+        # implementation and are ignored: this class IS one fused launch); the ones that change the arithmetic are rejected by name
+        for name, val in (("maximize", maximize), ("capturable", capturable), ("differentiable", differentiable),
+                          ("decoupled_weight_decay", decoupled_weight_decay)):
+            if val:
+                raise ValueError("hcflow_amd.optim.Adam: %s=True is not implemented; use torch.optim.Adam for it" % name)
         if not 0.0 <= lr:
             raise ValueError("Invalid learning rate: %r" % (lr,))
         if not 0.0 <= eps:
@@ -192,8 +199,11 @@ class Adam(torch.optim.Optimizer):
             tab["grad"] = g[seg] + (4 * _CHUNK * k).astype(np.uint64)
             tab["offset"] = (o[seg] + _CHUNK * k).astype(np.uint32)
             tab["n"] = np.minimum(_CHUNK, n[seg] - _CHUNK * k).astype(np.uint32)
-            host = torch.from_numpy(tab.view(np.uint8).reshape(-1)).pin_memory()
-            dev = host.to(fl.device, non_blocking=True)
+            host = torch.from_numpy(tab.view(np.uint8).reshape(-1))
+            # synchronous upload: a cached table is launched against on WHATEVER stream is current at a later step() (a training
+            # loop may move into torch.cuda.stream(side) after step 1), so the copy must not be ordered on one stream only
+            # (tables are rebuilt only when the gradient pointers change)
+            dev = host.to(fl.device, non_blocking=False)
             tables.append((int(act[sel][0]), dev, len(seg), host))
         return tables
 
@@ -211,6 +221,10 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad
                 if g is None:
                     continue
+                if g.dtype is not torch.float32 or not g.is_contiguous() or g.numel() != fl.numel[i]:
+                    # (checked on every step, not only when a chunk table is built: a table cached for these pointers must not be
+                    #  replayed over a gradient that has since become strided / expanded / cast)
+                    raise _lib.HcfError("hcflow_amd.optim.Adam: gradient %d is not a dense contiguous fp32 tensor" % i)
                 ptrs[i] = g.data_ptr()
                 active.append(i)
                 if p.data_ptr() != fl.pptr[i]:                  # someone re-pointed p.data (a manual swap, a cast and back): take it back in
@@ -267,7 +281,7 @@ def _grad_runs(params):
         raise _lib.HcfError("hcflow_amd.optim: gradients live on %s; this package runs on the GPU only" % (gs[0].device,))
     f32 = torch.float32
     for g in gs:                                         # (a ~1500-iteration host loop per step: two calls per tensor)
-        if g.dtype != f32:
+        if g.dtype != f32 or not g.is_contiguous():       # (an expanded / strided gradient inside a run: torch's route)
             return None
         ptr = g.data_ptr()
         if first is None or ptr != nxt:
@@ -292,12 +306,13 @@ def _grad_runs(params):
 
 
 @torch.no_grad()
-def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False):
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
     """``torch.nn.utils.clip_grad_norm_`` (HCFlow_SR_model.gradient_clip :293-294) on the flat gradient: one norm, one scale."""
     params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
     runs = _grad_runs(params)
     if runs is None:
-        return torch.nn.utils.clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite)
+        return torch.nn.utils.clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite,
+                                              foreach=foreach)
     if not runs:
         return torch.tensor(0.0)
     norms = [torch.linalg.vector_norm(r, float(norm_type)) for r in runs]
@@ -312,11 +327,11 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
 
 
 @torch.no_grad()
-def clip_grad_value_(parameters, clip_value):
+def clip_grad_value_(parameters, clip_value, foreach=None):
     """``torch.nn.utils.clip_grad_value_`` (HCFlow_SR_model.gradient_clip :291-292) on the flat gradient."""
     params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
     runs = _grad_runs(params)
     if runs is None:
-        return torch.nn.utils.clip_grad_value_(params, clip_value)
+        return torch.nn.utils.clip_grad_value_(params, clip_value, foreach=foreach)
     for r in runs:
         r.clamp_(min=-float(clip_value), max=float(clip_value))

@@ -123,6 +123,65 @@ def test_rescaling_roundtrip_full_size_vs_cpu_oracle():
     _check_inverse(cfg, p, net, lrq, 1.0, eps, "Rescaling_DF2K_4X B=1 HR 640x640 decode")
 
 
+def test_config2_b16_timed_configuration_vs_cpu_oracle():
+    """The configuration bench.py TIMES (BASELINE config 2: full depth, B = 16, LR 160x160, tau 0.8, module default f16x3):
+    kernel routing depends on the batch (hcf_engine.hip run_rdb: conv_wino_rounds_ok(B, H, W, ...) gates the fat launches), so the
+    B = 1 / 2 oracle comparisons above do not cover the schedule of the timed pass. Every op is per-sample
+    (HCFlowNet_SR_arch.py:70-75, thops.sum(dim=[1,2,3])), so samples {0, 7, 15} of ONE B = 16 engine call are compared with
+    three B = 1 oracle passes on the same LR / eps slices."""
+    cfg, p, net = _net("SR_DF2K_4X", 1234)
+    _threads()
+    B, tau = 16, 0.8
+    g = torch.Generator().manual_seed(1616)
+    lr = torch.rand(B, 3, 160, 160, generator=g)
+    eps = [torch.randn(s, generator=g) * tau for s in eps_shapes(cfg, B, 160, 160)]
+    try:
+        with torch.no_grad():
+            net.set_precision("f16x3")
+            n0 = net.engine().fallback_count()
+            raw = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=tau, eps=eps, clamp=False).cpu()
+            out = net(lr=lr.cuda(), z=None, u=None, eps_std=tau, reverse=True, eps=eps).cpu()
+            assert net.engine().fallback_count() == n0, "f16x3 range fallback on the seeded weights"
+            worst = 0.0
+            for b in (0, 7, 15):
+                ref_raw = O.sr_inverse(lr[b:b + 1], p, cfg, tau, [e[b:b + 1] for e in eps], clamp=False)
+                scale = max(1.0, float(ref_raw.abs().max()))
+                d_raw, d_out = maxdiff(raw[b:b + 1], ref_raw), maxdiff(out[b:b + 1], ref_raw.clamp(0, 1))
+                worst = max(worst, d_raw)
+                assert d_raw <= 1e-4 * scale, (b, d_raw, scale)
+                assert d_out <= 1e-4, (b, d_out)
+        print("full-size parity SR_DF2K_4X B=16 (timed configuration, f16x3) samples 0/7/15: max|HIP - CPU oracle| %.2e" % worst)
+    finally:
+        net.set_precision("exact")
+
+
+def test_config4_shard_b8_vs_cpu_oracle():
+    """BASELINE config 4 at its per-GPU shard size (B = 8, HR 640x640, module default f16x3): one sample of the B = 8 forward ->
+    Quant -> inverse round trip against the oracle's B = 1 passes (HCFlowNet_Rescaling_arch.py:26-54)."""
+    cfg, p, net = _net("Rescaling_DF2K_4X", 1234)
+    _threads()
+    B, b = 8, 5
+    g = torch.Generator().manual_seed(6408)
+    hr = torch.rand(B, 3, 640, 640, generator=g)
+    eps = [torch.randn(s, generator=g) for s in eps_shapes(cfg, B, 160, 160)]
+    try:
+        with torch.no_grad():
+            net.set_precision("f16x3")
+            n0 = net.engine().fallback_count()
+            lr_hat, z1, z2 = net(hr=hr.cuda(), reverse=False)
+            lr_ref, z1_ref, z2_ref = O.rescale_forward(hr[b:b + 1], p, cfg)
+            assert maxdiff(lr_hat[b:b + 1], lr_ref) <= 1e-4
+            assert maxdiff(z1[b:b + 1], z1_ref) <= 1e-4 * max(1.0, float(z1_ref.abs().max()))
+            assert maxdiff(z2[b:b + 1], z2_ref) <= 1e-4 * max(1.0, float(z2_ref.abs().max()))
+            lrq = ((lr_hat.clamp(0, 1) * 255.).round() / 255.).cpu()
+            raw = net.reverse_flow_diracLR(lrq.cuda(), None, None, eps_std=1.0, eps=eps, clamp=False).cpu()
+            ref_raw = O.rescale_inverse(lrq[b:b + 1], p, cfg, 1.0, [e[b:b + 1] for e in eps], clamp=False)
+            assert maxdiff(raw[b:b + 1], ref_raw) <= 1e-4 * max(1.0, float(ref_raw.abs().max()))
+            assert net.engine().fallback_count() == n0
+    finally:
+        net.set_precision("exact")
+
+
 def test_config2_forced_range_fallback_returns_the_exact_kernels_bits():
     """BASELINE config 2 (full depth, B = 16, LR 160x160, tau 0.8) with ONE activation beyond the f16 range: the default policy
     ("sync") re-runs the whole pass on the exact fp32-MFMA kernels before the call returns -- the output is bit-identical to

@@ -187,6 +187,40 @@ def test_lu_optimiser_steps_refresh_the_composed_weight_on_the_device():
     assert abs(float(n1) - float(n2)) <= 1e-5 * abs(float(n2))
 
 
+def test_lu_state_dict_with_other_pivoting_after_a_first_call():
+    """net.load_state_dict(ckpt) AFTER the engine has run: a checkpoint's p / sign_s (the fixed buffers of the LU form,
+    Permutations.py:46-55) differ from the random init's pivoting. The data pointers are unchanged and only _version moves, so
+    the module must not take the device-side refresh (which re-reads parameters only) -- the outputs must equal the oracle's on
+    the NEW state dict."""
+    from oracle import hcflow_oracle as O
+    from hcflow_amd.config import eps_shapes
+    cfg = preset("SR_4X_tiny_LU")
+    p_a, p_b = cached_params("SR_4X_tiny_LU", 91), cached_params("SR_4X_tiny_LU", 93)
+    key = "flow.layers.1.permute.p"
+    assert not torch.equal(torch.as_tensor(p_a[key]), torch.as_tensor(p_b[key])) or \
+        not torch.equal(torch.as_tensor(p_a["flow.layers.1.permute.sign_s"]), torch.as_tensor(p_b["flow.layers.1.permute.sign_s"]))
+    net = _net(cfg, p_a)
+    g = torch.Generator().manual_seed(11)
+    lr = torch.rand(2, 3, 12, 10, generator=g)
+    eps = [torch.randn(s, generator=g) * 0.8 for s in eps_shapes(cfg, 2, 12, 10)]
+    with torch.no_grad():
+        out_a = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.8, eps=eps, clamp=False)
+        ref_a = O.sr_inverse(lr, p_a, cfg, 0.8, eps, clamp=False)
+        assert maxdiff(out_a, ref_a) <= 1e-4 * max(1.0, float(ref_a.abs().max()))
+        ptr = net.flow.layers[1].permute.p.data_ptr()
+        net.load_state_dict(p_b, strict=True)                      # in place: same storage, new contents
+        assert net.flow.layers[1].permute.p.data_ptr() == ptr
+        out_b = net.reverse_flow_diracLR(lr.cuda(), None, None, eps_std=0.8, eps=eps, clamp=False)
+        ref_b = O.sr_inverse(lr, p_b, cfg, 0.8, eps, clamp=False)
+        assert maxdiff(out_b, ref_b) <= 1e-4 * max(1.0, float(ref_b.abs().max())), maxdiff(out_b, ref_b)
+        hr = torch.rand(2, 3, 48, 40, generator=g)
+        noise = torch.rand(2, 3, 48, 40, generator=g)
+        lr_ref, _ = O.sr_forward(hr, torch.zeros(2, 3, 12, 10), p_b, cfg, noise=noise)
+        _, nll_ref = O.sr_forward(hr, lr_ref, p_b, cfg, noise=noise)
+        _, nll = net(hr=hr.cuda(), lr=lr_ref.cuda(), reverse=False, noise=noise.cuda())
+        assert abs(float(nll) - float(nll_ref)) <= 1e-4
+
+
 def test_lu_oracle_parity_on_fresh_inputs_full_width():
     """HIP path vs the CPU oracle on new seeded inputs, LU in the x8 net (C = 48 steps: the widest composition)."""
     from oracle import hcflow_oracle as O

@@ -115,8 +115,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < w.size(); ++i) w[i] = hashf(i, 3) * 0.5f / sqrtf((float)cin * 9.f);
     for (int i = 0; i < P.cout; ++i) { bias[i] = hashf(i, 5) * 0.1f; scale[i] = 1.f + 0.1f * hashf(i, 6); }
     std::vector<uint16_t> pk;
-    const int ver = ((version == 4 || version == 5) && P.cout != 64) ? 2 : version;         // v4 / v5 are the 64-output-channel kernels
-    if (!((ver == 4 || ver == 5) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
+    const int ver = ((version >= 4) && P.cout != 64) ? 2 : version;         // v4 / v5 / v6 (6, 7) are the 64-output-channel kernels         // v4 / v5 are the 64-output-channel kernels
+    if (!((ver >= 4) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
