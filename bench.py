@@ -12,6 +12,10 @@ followed for N > 1 by the RCCL all-gather of the output batch (north_star). Inpu
 HBM before the timed region. N > 1 is launched by torch.distributed.run, one rank per GPU, each
 rank samples its own shard (weak scaling, no data-path collective besides the output gather).
 
+Other lines the driver can ask for with one flag each (none of them has been measured at N > 1: no multi-GPU node was available):
+    --preset Rescaling_DF2K_4X --batch 8        BASELINE config 4 (rescaling forward -> Quant -> inverse, 64 images over 8 GPUs)
+    --workload train [--optim native]           BASELINE config 5 (DDP NLL training step, 16 HR patches per GPU, global batch 128)
+
 `value`, `ms_per_step` and `roofline` belong to the MODULE'S DEFAULT conv numerics (f16x3: fp32-equivalent split products
 on the f16 matrix cores, hcflow_amd/arch.py); `other_precision` repeats the same timed region (same K steps) on the exact
 fp32-MFMA kernels with its own roofline block, and `precision.check` gives the deviation between the two on the same draws.
@@ -84,6 +88,13 @@ def main():
     ap.add_argument("--lr-size", type=int, default=160)
     ap.add_argument("--tau", type=float, default=0.8)
     ap.add_argument("--preset", default="SR_DF2K_4X")
+    ap.add_argument("--workload", default="sample", choices=["sample", "train"],
+                    help="sample: the headline (inverse sampling; --preset Rescaling_DF2K_4X = config 4's round trip); train: BASELINE "
+                         "config 5, the DDP NLL training step (HR 160x160 patches, --batch per GPU, global batch = N x batch)")
+    ap.add_argument("--optim", default="torch", choices=["torch", "native"],
+                    help="--workload train: torch = the reference caller's own torch.optim.Adam + clip_grad_norm_ (the headline of that "
+                         "line); native = hcflow_amd.optim. The other one is timed beside it")
+    ap.add_argument("--hr-size", type=int, default=160, help="--workload train: HR patch size (datasets.train.GT_size)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "exact"],
                     help="headline conv numerics: f16x3 = the module default (fp32-equivalent split products on f16 MFMA); "
                          "exact = fp32 MFMA. The other mode is timed over the same number of steps and reported beside it")
@@ -115,6 +126,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "train":
+        train_workload(args, dev, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     cfg = preset(args.preset)
     params = make_params(cfg, 1234)
@@ -305,6 +322,104 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def train_workload(args, dev, world, rank):
+    """BASELINE.json config 5 on N GPUs: the NLL training step of train_HCFlow.py on the SR x4 net, one process per GPU, the net
+    wrapped in DistributedDataParallel(netG, device_ids=[local]) exactly as HCFlow_SR_model.py:33-36 does, step = forward (by
+    keyword through DDP) + nll.backward() (DDP's hooks all-reduce the 92.9 MB of gradients over RCCL) + clip_grad_norm_ +
+    Adam.step() as :195-202 / :289-294 (hcflow_amd/dist.py: train_step). Per-rank batch fixed (weak scaling), synthetic HR
+    patches, LR = bicubic / 4 as the reference's dataset does. Timing contract as the sampling line (dist.timed_region)."""
+    import torch
+    import torch.distributed as dist
+    from hcflow_amd import HCFlowNet_SR, preset, make_params
+    from hcflow_amd.dist import wrap_ddp, train_step, timed_region, grad_allreduce_bytes
+    from hcflow_amd import optim as hopt
+    cfg = preset(args.preset)
+    assert cfg.sr, "--workload train is the SR NLL step (config 5)"
+    B, H = args.batch, args.hr_size
+    g = torch.Generator().manual_seed(2000 + rank)
+    hr = torch.rand(B, 3, H, H, generator=g).to(dev)
+    lr = torch.nn.functional.interpolate(hr, scale_factor=1.0 / cfg.scale, mode="bicubic", align_corners=False).clamp(0, 1)
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "exact" else PEAK_F16_MFMA_TFLOPS / 3
+
+    def build():
+        with contextlib.redirect_stdout(sys.stderr):
+            net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(make_params(cfg, 1234), strict=True)      # every rank: the same seeded weights (DDP would broadcast rank 0's)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to(dev).train().set_precision(args.precision)
+        return net, wrap_ddp(net, dev)
+
+    def run(native):
+        net, ddp = build()
+        ps = [q for q in net.parameters() if q.requires_grad]        # the reference builds its optimiser AFTER the wrap (:118)
+        if native:
+            opt, clip = hopt.Adam(ps, lr=2.5e-4, betas=(0.9, 0.99)), hopt.clip_grad_norm_
+        else:
+            opt, clip = torch.optim.Adam(ps, lr=2.5e-4, betas=(0.9, 0.99)), torch.nn.utils.clip_grad_norm_
+        keep = {}
+
+        def one(i):
+            keep["nll"] = train_step(ddp, hr, lr, opt, clip, 100.0)
+        for i in range(max(2, args.warmup)):                          # >= 2: step 1 builds plans / buckets, step 2 sees a device refresh
+            one(i)
+        dt = timed_region(one, args.steps, first=args.warmup)
+        nll = float(keep["nll"])
+        assert nll == nll, "NLL is NaN"
+        # phase split of ONE more step with host syncs between the phases (outside the timed region: the syncs break the overlap
+        # of the all-reduce with the optimiser's host work)
+        sync = torch.cuda.synchronize
+        sync(); t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        _, l = ddp(hr=hr, lr=lr, reverse=False)
+        sync(); t1 = time.perf_counter()
+        l.backward()
+        sync(); t2 = time.perf_counter()
+        clip(net.parameters(), 100.0)
+        opt.step()
+        sync(); t3 = time.perf_counter()
+        res = {"value": round(world * B * args.steps / dt, 3), "ms_per_step": round(1e3 * dt / args.steps, 3), "nll_last": round(nll, 5),
+               "phases_ms_one_synchronised_step": {"forward_incl_refresh": round(1e3 * (t1 - t0), 2),
+                                                   "backward_incl_allreduce": round(1e3 * (t2 - t1), 2),
+                                                   "clip_adam": round(1e3 * (t3 - t2), 2)},
+               "mfma_frac": round(B * args.steps / dt * GFLOP_TRAIN_SAMPLE / 1e3 / peak, 4),
+               "allreduce_MB_per_step": round(grad_allreduce_bytes(net) / 1e6, 1) if world > 1 else 0.0,
+               "activation_arena_GB": round(net.engine().workspace_bytes() / 2 ** 30, 2)}
+        del opt, ddp, net
+        torch.cuda.empty_cache()
+        return res
+
+    first = run(args.optim == "native")
+    try:
+        second = run(args.optim != "native")
+    except Exception as e:  # noqa: BLE001 -- the side line must not cost the headline
+        second = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    names = {True: "hcflow_amd.optim.Adam + hcflow_amd.optim.clip_grad_norm_ (INTEGRATION.md: two lines of the caller switched)",
+             False: "torch.optim.Adam + torch.nn.utils.clip_grad_norm_ (the reference caller's own lines, unchanged)"}
+    if rank == 0:
+        line = {
+            "metric": "training samples/sec (NLL step, General-SR x4, HR %dpx patches, DDP)" % H, "value": first["value"],
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup),
+            "ms_per_step": first["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "exact" else "f32 via f16x3 split (hi/lo f16 products, f32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: %s NLL training step (train_HCFlow.py / HCFlow_SR_model.optimize_parameters), "
+                                   "batch %d/GPU of HR %dx%d patches (LR %dx%d), DistributedDataParallel(netG, device_ids=[local]) "
+                                   "for N>1, gradients all-reduced over RCCL" % (args.preset, B, H, H, H // cfg.scale, H // cfg.scale),
+                       "global_batch": world * B, "hr_size": H, "parallelism": "ddp%d" % world,
+                       "optimizer": names[args.optim == "native"]},
+            "detail": first,
+            "other_optimizer": dict(second, optimizer=names[args.optim != "native"]),
+            "roofline": {"bound": "mfma", "achieved": round(first["mfma_frac"] * peak, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": first["mfma_frac"], "traffic": None,
+                         "note": "whole step: algorithmic FLOPs (forward 184.27 GFLOP per sample x ~3 with the backward pass, BASELINE.md "
+                                 "section 2) / step time, per GPU; per-kernel tables of this step: profiles/rNN_kernel_stats_train_step_*"},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line), flush=True)
 
 
 def other_configs(dev, params_sr4, steps, mode):

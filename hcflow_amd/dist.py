@@ -152,3 +152,38 @@ def timed_region(step_fn: Callable[[int], object], steps: int, first: int = 0, g
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
         dt = float(tmax.item())
     return dt
+
+
+# ---------------------------------------------------------------- config 5: the DDP NLL training step (bench.py --workload train)
+def wrap_ddp(net, device: Optional[torch.device] = None, group=None):
+    """The reference's wrap (HCFlow_SR_model.py:33-36): ``DistributedDataParallel(netG, device_ids=[torch.cuda.current_device()])``
+    when a process group with more than one rank exists, the bare module otherwise (the reference's non-distributed branch is
+    ``DataParallel`` over one device: the same single replica). CPU tensors (the gloo tests) take DDP's device_ids=None form."""
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not on:
+        return net
+    from torch.nn.parallel import DistributedDataParallel
+    if device is not None and device.type == "cuda":
+        return DistributedDataParallel(net, device_ids=[device.index if device.index is not None else torch.cuda.current_device()],
+                                       process_group=group)
+    return DistributedDataParallel(net, process_group=group)
+
+
+def grad_allreduce_bytes(net) -> int:
+    """Bytes DDP all-reduces per step: every trainable tensor's gradient, fp32 (config 5: 92.9 MB for the SR x4 net)."""
+    mod = net.module if hasattr(net, "module") else net
+    return int(sum(p.numel() * p.element_size() for p in mod.parameters() if p.requires_grad))
+
+
+def train_step(net, hr: torch.Tensor, lr: torch.Tensor, optimizer, clip_fn=None, max_norm: float = 100.0, **fwd_kw):
+    """One optimisation step exactly as the reference's caller runs it (HCFlow_SR_model.optimize_parameters :184-205 with the
+    NLL loss only, gradient_clip :289-294): zero_grad, ``netG(hr=, lr=, reverse=False)`` by keyword (through DDP when wrapped:
+    its hooks all-reduce the gradients during backward), ``nll.backward()``, ``clip_grad_norm_``, ``optimizer.step()``.
+    Returns the detached loss tensor (no host sync here)."""
+    optimizer.zero_grad(set_to_none=True)
+    _, nll = net(hr=hr, lr=lr, reverse=False, **fwd_kw)
+    nll.backward()
+    mod = net.module if hasattr(net, "module") else net
+    (clip_fn or torch.nn.utils.clip_grad_norm_)(mod.parameters(), max_norm)
+    optimizer.step()
+    return nll.detach()

@@ -198,3 +198,77 @@ def test_sharded_rescale_roundtrip_and_bench_step_gloo_world2(B):
     for p_ in procs:
         p_.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _StubSR(torch.nn.Module):
+    """The SR class's training call surface (HCFlowNet_SR_arch.py:34-35: forward(hr=, lr=, reverse=False) -> (LR^, nll scalar)) on a
+    two-layer stand-in, so that the config-5 harness logic runs on CPU."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.a = torch.nn.Conv2d(3, 4, 3, padding=1)
+        self.b = torch.nn.Conv2d(4, 3, 1)
+        self.frozen = torch.nn.Parameter(torch.ones(5), requires_grad=False)      # (the rescaling nets' Haar filters are frozen)
+
+    def forward(self, hr=None, lr=None, z=None, u=None, eps_std=None, add_gt_noise=False, step=None, reverse=False, training=True):
+        assert not reverse and hr is not None and lr is not None
+        y = self.b(torch.relu(self.a(hr)))
+        y = torch.nn.functional.avg_pool2d(y, 4)
+        return y.detach(), ((y - lr) ** 2).mean()
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hcflow_amd.dist import wrap_ddp, train_step, timed_region, grad_allreduce_bytes
+        net = _StubSR()
+        ddp = wrap_ddp(net, torch.device("cpu"))
+        ok = type(ddp).__name__ == "DistributedDataParallel" and ddp.module is net
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-2, betas=(0.9, 0.99))
+        g = torch.Generator().manual_seed(100 + rank)                   # every rank its own shard of the global batch
+        hr = torch.rand(4, 3, 16, 16, generator=g)
+        lr = torch.rand(4, 3, 4, 4, generator=g)
+        losses = []
+
+        def one(i):
+            losses.append(float(train_step(ddp, hr, lr, opt, None, 100.0)))
+        dt = timed_region(one, 3, first=0)
+        ok = ok and len(losses) == 3 and losses[2] < losses[0] and dt > 0
+        # DDP averaged the gradients: the replicas hold identical parameters after the steps although their data differ
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        ok = ok and torch.equal(both[0], both[1])
+        ok = ok and grad_allreduce_bytes(ddp) == 4 * sum(p.numel() for p in net.parameters() if p.requires_grad)
+        ok = ok and net.frozen.grad is None
+        q.put((rank, bool(ok), losses[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_ddp_train_step_harness_gloo_world2():
+    """bench.py --workload train on two gloo ranks with a stand-in net: the reference's wrap (HCFlow_SR_model.py:33-36), the
+    step of optimize_parameters (:184-205, :289-294) and the timing contract (hcflow_amd/dist.py: wrap_ddp, train_step,
+    timed_region); replicas stay in lock step on different shards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p_ in procs:
+        p_.join(60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)]
+    assert res[0][2] != res[1][2]                    # different shards, different first losses
+
+
+def test_wrap_ddp_without_a_process_group_is_the_module():
+    from hcflow_amd.dist import wrap_ddp, grad_allreduce_bytes
+    net = _StubSR()
+    assert wrap_ddp(net, torch.device("cpu")) is net
+    assert grad_allreduce_bytes(net) == 4 * sum(p.numel() for p in net.parameters() if p.requires_grad)

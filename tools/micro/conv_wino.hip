@@ -10,6 +10,7 @@
 #include "hcf_conv_wino.h"
 #include "hcf_conv_wino_v1.h"      // version 1 of the series (tools/micro only)
 #include "hcf_conv_wino_v5.h"      // version 5: the ping-pong experiment (tools/micro only)
+#include "hcf_conv_wino_v6.h"      // version 6 / 7: the row phase pipelined under the position loop (round 5; tools/micro only)
 
 using namespace hcf::wino;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -143,7 +144,7 @@ int main(int argc, char** argv) {
       a.f_w = dfw; a.f_bias = dbias2; a.f_scale = dscale2; a.f_act = 1;
     }
     unsigned long long* dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128)); a.dbg = dbg;
-    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
+    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : ver >= 6 ? launch_v6(a, ncu, 0, ver - 6) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -168,9 +169,9 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : ver >= 6 ? launch_v6(a, ncu, 0, ver - 6) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : ver >= 6 ? launch_v6(a, ncu, 0, ver - 6) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;
