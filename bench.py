@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" dense
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec
+ACHIEVABLE_HBM_GBS = 6300.0           # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy)
 GFLOP_PER_IMAGE = 2948.25             # SR x4 inverse, LR 160^2 -> one 640^2 image
 # (label, taps, n-tiles, kind) of the conv instantiations a pass launches; kind: see include/hcflow.h hcf_conv_time_ms (5 = the persistent small-K FCN kernel)
 # + the keys of that instantiation in profiles/rNN_traffic_pmc.json (tools/pmc_traffic.py)
@@ -65,7 +66,8 @@ VARIANTS = {
               ("hcf::wino::conv_wino4_kernel<3> conditional FCN conv1 (Winograd, [z1 padded to 16 | 128 features] -> 64) + conv2 1x1 in "
                "its epilogue", 9, 2, 6, ["wino4<3>"]),
               ("hcf::fcn12::fcn12_kernel<false> FCN conv1 3x3 (<= 16 in-ch) + conv2 1x1, persistent, weights in registers", 9, 2, 5, ["fcn12"]),
-              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2, []),
+              ("hcf::f16x3::conv_f16x3_kernel<1,true,false,false,TAILC,8,false> FCN conv3 + flow-step tail", 9, 1, 2,
+               ["f16x3<1>+tail8", "f16x3<1>+tail12", "f16x3<1>+tail24"]),
               ("hcf::f16x3::conv_f16x3_kernel<2,true,true,false,0,8,false> conv_first on upsampled LR (UP)", 9, 2, 3, ["f16x3<2>+up"]),
               ("hcf::conv_mfma_kernel<1,*,true> 1x1 convs left on the exact fp32 kernel", 1, 0, -1, [])],
     "exact": [("hcf::conv_mfma_kernel<9,2,true> 3x3, 33..64 out-ch", 9, 2, -1, ["exact<9,2>"]),
@@ -168,7 +170,7 @@ def main():
             if world > 1:
                 dist.all_gather_into_tensor(out_all, out)     # RCCL over xGMI: output batch only
         else:
-            out = gathered_step(net, lr, args.tau, 4242 + it, out_all)   # sample this rank's shard + RCCL all-gather (N > 1)
+            out = gathered_step(net, lr, args.tau, 4242 + it, out_all, overlap=True)   # this rank's shard + async RCCL all-gather (N > 1)
         return out
 
     def timed(mode, warmup, steps):
@@ -201,34 +203,61 @@ def main():
                                  "algorithmic_GBps": round((vby / 1e9) / (vms / 1e3), 1)})
         ms_all, n_all, fl_all, by_all = eng.conv_time(0, 0, reset=True)
         variants.sort(key=lambda v: -v["ms_per_step"])
-        dom = variants[0]                        # the instantiation with the largest total time IS the dominant kernel
         if mode == "exact":
             peak, pnote = PEAK_F32_MFMA_TFLOPS, "fp32 matrix peak (MI355X_MICROARCH.md)"
         else:
             peak = PEAK_F16_MFMA_TFLOPS / 3
             pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts ALGORITHMIC "
-                     "flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that")
-        if "wino" in dom["kernel"]:
-            pnote += ("; this kernel is the Winograd F(2x2,3x3) form: it executes 3 / 2.25 = 1.33x the algorithmic flops on the "
-                      "matrix cores (VALU-issue bound), the nominal 833 stays the yardstick for comparability with the direct form")
-        traffic, tnote = None, ("not measured in this run (PMC counters need separate rocprofv3 --pmc passes: "
-                                "profiles/ holds them per round)")
+                     "flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that (Winograd families: 3 / 2.25 = 1.33x)")
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.py), replayed
+        # from profiles/ for EVERY family that has an entry; only valid for the configuration they were collected on
+        tj, tfile = None, None
         try:
-            tfile = next(f for f in ("r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            tfile = next(f for f in ("r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-            ents = [tj["kernels"][k] for k in dom["_tkeys"] if k in tj["kernels"]]
-            if ents and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:       # launch-weighted mean over the instantiation's keys
-                traffic = round(sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) /
-                                sum(e["launches_sampled"] for e in ents) / 1e9, 4)
-                tnote = "GB per launch, REPLAYED from profiles/" + tfile + " (" + tj["source"] + "), not measured in this run"
-        except (OSError, KeyError, ValueError, StopIteration):
+        except (OSError, ValueError, StopIteration):
             pass
+        tvalid = tj is not None and args.preset == "SR_DF2K_4X" and B == 16 and h == 160
+        for v in variants:
+            wino = "wino" in v["kernel"]
+            v["frac_of_yardstick"] = round(v["tflops"] / peak, 4)
+            if mode != "exact":
+                # the same algorithmic rate against the UN-derated dense f16 MFMA peak, and the share of that peak the matrix
+                # cores actually execute (3 MFMAs per product; the Winograd form needs 2.25x fewer products)
+                v["frac_of_dense_f16_peak"] = round(v["tflops"] / PEAK_F16_MFMA_TFLOPS, 4)
+                v["mfma_executed_frac"] = round(v["tflops"] * (3.0 / 2.25 if wino else 3.0) / PEAK_F16_MFMA_TFLOPS, 4)
+            v["traffic_GB_per_launch"] = None
+            try:
+                ents = [tj["kernels"][k] for k in v["_tkeys"] if k in tj["kernels"]] if tvalid else []
+                if ents:                                   # launch-weighted mean over the family's instantiations
+                    v["traffic_GB_per_launch"] = round(sum(e["hbm_bytes_per_launch"] * e["launches_sampled"] for e in ents) /
+                                                       sum(e["launches_sampled"] for e in ents) / 1e9, 4)
+            except (KeyError, TypeError, ZeroDivisionError):
+                pass
+            # which roofline this family sits closer to: matrix rate against the yardstick, or moved bytes (PMC when available,
+            # algorithmic otherwise) per measured launch time against the ACHIEVABLE HBM rate
+            gb = v["traffic_GB_per_launch"] if v["traffic_GB_per_launch"] is not None else v["algorithmic_GB_per_launch"]
+            hbm_frac = gb / (v["avg_launch_us"] * 1e-6) / ACHIEVABLE_HBM_GBS if v["avg_launch_us"] > 0 else 0.0
+            v["hbm_frac_of_achievable"] = round(hbm_frac, 4)
+            v["bound"] = "hbm" if hbm_frac > v["frac_of_yardstick"] else "mfma"
+        dom = variants[0]                        # the instantiation family with the largest total time IS the dominant kernel
+        traffic = dom["traffic_GB_per_launch"]
+        tnote = ("GB per launch, REPLAYED from profiles/" + tfile + " (" + tj["source"] + "), not measured in this run") if traffic is not None else \
+                ("not measured in this run (PMC counters need separate rocprofv3 --pmc passes: profiles/ holds them per round)")
+        if dom["bound"] == "hbm":
+            b_ach, b_peak, b_unit = round(dom["hbm_frac_of_achievable"] * ACHIEVABLE_HBM_GBS, 1), ACHIEVABLE_HBM_GBS, "GB/s"
+            b_frac = dom["hbm_frac_of_achievable"]
+        else:
+            b_ach, b_peak, b_unit, b_frac = dom["tflops"], round(peak, 1), "TFLOP/s", round(dom["tflops"] / peak, 4)
         block = {
-            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
-            "peak_note": pnote, "frac": round(dom["tflops"] / peak, 4), "traffic": traffic, "traffic_note": tnote,
+            "bound": dom["bound"], "kernel": dom["kernel"], "achieved": b_ach, "peak": b_peak, "unit": b_unit,
+            "peak_note": pnote, "frac": b_frac, "traffic": traffic, "traffic_note": tnote,
+            "frac_of_dense_f16_peak": dom.get("frac_of_dense_f16_peak"), "mfma_executed_frac": dom.get("mfma_executed_frac"),
             "algorithmic_GB_per_launch": dom["algorithmic_GB_per_launch"], "launches": dom["launches_per_step"] * steps,
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
-            "selection": "instantiation with the largest total time in the timed region",
+            "selection": "instantiation family with the largest total time in the timed region; `bound` = the larger of "
+                         "(algorithmic TFLOP/s / yardstick) and (bytes per launch / launch time / 6.3 TB/s achievable HBM), per family",
             "conv_kernels": [{k: v for k, v in x.items() if k != "_tkeys"} for x in variants],
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / steps, 3),
                           "tflops": round((fl_all / 1e12) / (ms_all / 1e3), 3) if ms_all > 0 else 0.0,
@@ -343,18 +372,18 @@ def train_workload(args, dev, world, rank):
     lr = torch.nn.functional.interpolate(hr, scale_factor=1.0 / cfg.scale, mode="bicubic", align_corners=False).clamp(0, 1)
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "exact" else PEAK_F16_MFMA_TFLOPS / 3
 
-    def build():
-        with contextlib.redirect_stdout(sys.stderr):
-            net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
-        net.load_state_dict(make_params(cfg, 1234), strict=True)      # every rank: the same seeded weights (DDP would broadcast rank 0's)
-        for m in net.modules():
-            if "ActNorm" in type(m).__name__:
-                m.inited = True
-        net = net.to(dev).train().set_precision(args.precision)
-        return net, wrap_ddp(net, dev)
+    params = make_params(cfg, 1234)
+    with contextlib.redirect_stdout(sys.stderr):
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(params, strict=True)                          # every rank: the same seeded weights (DDP would broadcast rank 0's)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to(dev).train().set_precision(args.precision)
+    ddp = wrap_ddp(net, dev)                                          # ONE module / engine / wrap for both optimiser variants
 
     def run(native):
-        net, ddp = build()
+        net.load_state_dict(params, strict=True)                      # both variants start from the same weights (in-place copy)
         ps = [q for q in net.parameters() if q.requires_grad]        # the reference builds its optimiser AFTER the wrap (:118)
         if native:
             opt, clip = hopt.Adam(ps, lr=2.5e-4, betas=(0.9, 0.99)), hopt.clip_grad_norm_
@@ -388,8 +417,7 @@ def train_workload(args, dev, world, rank):
                "mfma_frac": round(B * args.steps / dt * GFLOP_TRAIN_SAMPLE / 1e3 / peak, 4),
                "allreduce_MB_per_step": round(grad_allreduce_bytes(net) / 1e6, 1) if world > 1 else 0.0,
                "activation_arena_GB": round(net.engine().workspace_bytes() / 2 ** 30, 2)}
-        del opt, ddp, net
-        torch.cuda.empty_cache()
+        del opt
         return res
 
     first = run(args.optim == "native")
@@ -566,10 +594,13 @@ def cpu_baseline(cfg, params, h, passes):
     # pick the thread count that serves the CPU path best on this host (all logical CPUs is
     # pathological for this op mix: 31 s/image with 128 threads on a 2x64-core EPYC)
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64) if 1 <= c <= ncpu})   # more threads only get slower (measured)
+    phys = physical_cores() or ncpu
+    # candidates up to ALL physical cores; the full-size passes use the fastest (more threads only get slower for this
+    # op mix: oneDNN convs of 32..64 channels do not scale past ~16 threads; the calibration timings are part of the record)
+    cands = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= ncpu})
     small = torch.rand(1, 3, max(8, h // 4), max(8, h // 4), generator=g)
     best, threads = None, cands[0]
-    times = []
+    times, calib = [], {}
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
@@ -577,6 +608,7 @@ def cpu_baseline(cfg, params, h, passes):
             t0 = time.perf_counter()
             fn(small, params, cfg, 0.0)
             t = time.perf_counter() - t0
+            calib[str(c)] = round(t, 4)
             if best is None or t < best:
                 best, threads = t, c
         torch.set_num_threads(threads)
@@ -585,6 +617,13 @@ def cpu_baseline(cfg, params, h, passes):
             t0 = time.perf_counter()
             out = fn(lr, params, cfg, 0.0)
             times.append(time.perf_counter() - t0)
+        # batch throughput beside the single-patch latency ("both"): B = 2 of the same LR size, 2 timed passes
+        lr2 = torch.cat([lr, torch.rand(1, 3, h, h, generator=g)], 0)
+        t2 = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fn(lr2, params, cfg, 0.0)
+            t2.append(time.perf_counter() - t0)
     med = statistics.median(times)
     c_port = c_port_sample()
     cpu_model = ""
@@ -595,11 +634,37 @@ def cpu_baseline(cfg, params, h, passes):
                 break
     except OSError:
         pass
-    return ({"value": round(1.0 / med, 4), "unit": "HR images/s", "cores": threads, "kind": "port",
-            "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN): BASELINE config 1, B=1 LR %dx%d, tau=0, median of %d "
-                      "timed passes after warm-up, %d threads chosen from %s on a %d-CPU host" % (h, h, passes, threads, cands, ncpu),
-            "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times],
-             "spread_rel": round((max(times) - min(times)) / med, 3), "c_port": c_port}, lr, out)
+    return ({"value": round(1.0 / med, 4), "unit": "HR images/s", "cores": threads, "threads": threads, "physical_cores": phys,
+             "logical_cpus": ncpu, "kind": "port",
+             "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN): BASELINE config 1, B=1 LR %dx%d, tau=0, median of %d "
+                       "timed passes after warm-up, %d threads = the fastest of %s on a host with %d physical cores / %d logical CPUs "
+                       "(calibration on a %dx%d patch: seconds per pass in `thread_calibration_s`)"
+                       % (h, h, passes, threads, cands, phys, ncpu, small.shape[2], small.shape[3]),
+             "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times],
+             "spread_rel": round((max(times) - min(times)) / med, 3), "thread_calibration_s": calib,
+             "batch2_throughput": {"value": round(2.0 / min(t2), 4), "unit": "HR images/s", "pass_times_s": [round(t, 3) for t in t2],
+                                   "sample": "same net, B=2 LR %dx%d, tau=0, best of 2 passes, %d threads" % (h, h, threads)},
+             "c_port": c_port}, lr, out)
+
+
+def physical_cores():
+    """Physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo (None when it cannot be read)."""
+    try:
+        seen, pid, cid = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    seen.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            seen.add((pid, cid))
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def c_port_sample():

@@ -22,7 +22,7 @@ FLAG_REUSE_COND = 8
 # every symbol include/hcflow.h declares (tests/test_cabi_cpu.py checks the .so exports them all)
 SYMBOLS = [
     "hcf_create", "hcf_destroy", "hcf_last_error", "hcf_param_count", "hcf_param_info",
-    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_inverse_ex", "hcf_check_range", "hcf_forward_sr", "hcf_forward_rescale",
+    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_inverse_ex", "hcf_check_range", "hcf_check_range_samples", "hcf_forward_sr", "hcf_forward_rescale",
     "hcf_workspace_bytes", "hcf_weight_bytes", "hcf_profile_convs", "hcf_conv_time_ms",
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     lib.hcf_inverse.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, fp, i32, i32, i32, u32, vp]
     lib.hcf_inverse_ex.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, i64, fp, i32, i32, i32, u32, vp]
     lib.hcf_check_range.argtypes = [vp, C.POINTER(i32)]
+    lib.hcf_check_range_samples.argtypes = [vp, C.POINTER(i32), C.POINTER(u32)]
     lib.hcf_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.hcf_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, u32, vp]
     lib.hcf_workspace_bytes.argtypes = [vp]
@@ -249,6 +250,13 @@ class Engine:
         o = C.c_int32(0)
         check(self.lib.hcf_check_range(self._h, C.byref(o)), self._h, "hcf_check_range")
         return bool(o.value)
+
+    def check_range_samples(self):
+        """(overflowed, slots): as check_range, plus the bit set of flagged sample slots -- bit (b mod 30) for sample b of its call
+        (include/hcflow.h: hcf_check_range_samples)."""
+        o, m = C.c_int32(0), C.c_uint32(0)
+        check(self.lib.hcf_check_range_samples(self._h, C.byref(o), C.byref(m)), self._h, "hcf_check_range_samples")
+        return bool(o.value), int(m.value)
 
     def range_probe(self, enable: bool):
         check(self.lib.hcf_debug_range_probe(self._h, int(enable)), self._h, "hcf_debug_range_probe")

@@ -548,16 +548,28 @@ class _EngineModule(nn.Module):
     def _params(self):
         return [p for _, p in self._tensors()]
 
-    def _run_checked(self, eng, idx, call, what):
-        """One inference pass through the C ABI (``call()`` enqueues it and returns the status) under the range-check policy."""
+    def _run_checked(self, eng, idx, call, what, batch=0, call_sample=None):
+        """One inference pass through the C ABI (``call()`` enqueues it and returns the status) under the range-check policy.
+        ``call_sample(b)`` (optional) enqueues the pass for sample ``b`` of the batch alone: every op of the path is per-sample
+        (HCFlowNet_SR_arch.py:70-75), so an activation beyond the f16 range costs an exact re-run of the samples whose tiles saw
+        it (B = 1 passes on the fp32-MFMA kernels into the same output rows), not of the whole batch."""
         with torch.cuda.device(idx):
             _lib.check(call(), eng.handle, what)
-            if self._precision[0] == "f16x3" and self._range_check[0] == "sync" and eng.check_range():
-                eng.set_precision("exact")                   # an activation left the f16 range: redo this pass exactly
-                try:
+            if self._precision[0] != "f16x3" or self._range_check[0] != "sync":
+                return
+            over, slots = eng.check_range_samples()
+            if not over:
+                return
+            flagged = [b for b in range(batch) if (slots >> (b % 30)) & 1]
+            eng.set_precision("exact")                       # an activation left the f16 range: redo exactly
+            try:
+                if call_sample is not None and 0 < len(flagged) < batch:
+                    for b in flagged:
+                        _lib.check(call_sample(b), eng.handle, what + " (exact re-run of sample %d)" % b)
+                else:
                     _lib.check(call(), eng.handle, what + " (exact re-run)")
-                finally:
-                    eng.set_precision(self._precision[0])
+            finally:
+                eng.set_precision(self._precision[0])
 
     def _check_inference(self, reverse=False):
         if self._wants_grad():
@@ -675,6 +687,7 @@ class _EngineModule(nn.Module):
             return out
         shapes = eps_shapes(cfg, B, h, w)
         keep = []
+        keep_at = [None] * len(shapes)
         arr = (C.c_void_p * len(shapes))()
         if eps is not None:
             assert len(eps) == len(shapes)
@@ -685,6 +698,7 @@ class _EngineModule(nn.Module):
                 e = self._prep(e, dev)
                 assert tuple(e.shape) == tuple(s), (tuple(e.shape), s)
                 keep.append(e)
+                keep_at[i] = e
                 arr[i] = e.data_ptr()
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
@@ -704,9 +718,19 @@ class _EngineModule(nn.Module):
         else:
             self._cond_key.pop(idx, None)
         stream = self._stream(idx)
+
+        def one_sample(b):
+            # sample b alone: its LR row, its rows of the injected draws (or the same seed with its global sample index: the
+            # device draws are indexed by sample, hcf_inverse_ex), its output row; contiguous NCHW slices, no copies
+            arr1 = (C.c_void_p * len(shapes))()
+            for i, e in enumerate(keep_at):
+                arr1[i] = None if e is None else e[b:b + 1].data_ptr()
+            return eng.lib.hcf_inverse_ex(eng.handle, lr[b:b + 1].data_ptr(), arr1, len(shapes), tau, seed, int(sample_offset) + b,
+                                          out[b:b + 1].data_ptr(), 1, h, w, flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND),
+                                          stream)
         self._run_checked(eng, idx, lambda: eng.lib.hcf_inverse_ex(
             eng.handle, lr.data_ptr(), arr, len(shapes), tau, seed, int(sample_offset), out.data_ptr(), B, h, w, flags,
-            stream), "hcf_inverse")
+            stream), "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample)
         return out
 
     # convenience for benchmarks / multi-GPU sharding

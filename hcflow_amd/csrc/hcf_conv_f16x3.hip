@@ -479,7 +479,9 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
       for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);
   }
   if (__any(chk != chk)) {
-    if (lane == 0) atomicOr(a.ovf, 1);
+    // bit 0: some input left the f16 range; bit 1 + (sample mod 30): which sample's tile saw it (hcf_check_range_samples: the
+    // module re-runs only those samples exactly); a strip tile spans several samples: all of them
+    if (lane == 0) atomicOr(a.ovf, sw ? 0x7fffffff : (1 | (2 << (b % 30))));
   }
 
   if constexpr (TAILC > 0) {

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
   FCN_TILE_COORDS(t, tb, ty0, tx0)
   FCN_LOAD(tb, ty0, tx0)
   float chk = 0.f;
+  unsigned omask = 0;            // range flag of this lane: bit 0 + one bit per sample slot (as hcf_conv_f16x3.hip)
 
   for (; t < ntiles; t += gridDim.x) {
     const int b = tb, y0 = ty0, x0 = tx0;
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);
+    omask |= (chk != chk) ? (1u | (2u << (b % 30))) : 0u;      // per tile: a block walks tiles of several samples
+    chk = 0.f;
     // ---- output tile: pixel-major fp32 through LDS, 16-byte stores
     __syncthreads();                                   // every wave has read its layer-1 records
     float* const ldsT = reinterpret_cast<float*>(lds);
@@ -329,9 +332,7 @@ __global__ __launch_bounds__(256, 2) void fcn12_kernel(const ConvArgs a, const i
       }
     }
   }
-  if (__any(chk != chk)) {
-    if (lane == 0) atomicOr(a.ovf, 1);
-  }
+  if (omask) atomicOr(a.ovf, (int)omask);      // (rare path: every flagged lane reports its own samples)
 #undef FCN_TILE_COORDS
 #undef FCN_LOAD
 }

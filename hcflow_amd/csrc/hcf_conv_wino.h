@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
       }
     }
     if (__any(chk != chk)) {
-      if (lane == 0) atomicOr(a.ovf, 1);
+      if (lane == 0) atomicOr(a.ovf, 1 | (2 << (eb % 30)));     // bit 0 + the unit's sample slot (see hcf_conv_f16x3.hip)
     }
 #if defined(WINO_PROF)
     pw[3] += __builtin_readcyclecounter() - qe0;
@@ -748,7 +748,7 @@ __device__ __forceinline__ void wino64_epilogue(const Args& a, char* const lds, 
     }
   }
   if (__any(chk != chk)) {
-    if (lane == 0) atomicOr(a.ovf, 1);
+    if (lane == 0) atomicOr(a.ovf, 1 | (2 << (eb % 30)));       // bit 0 + the unit's sample slot (see hcf_conv_f16x3.hip)
   }
 }
 

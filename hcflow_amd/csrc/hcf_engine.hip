@@ -1481,13 +1481,16 @@ struct hcf_engine {
   }
   // 1: some f16x3 pass since the last check saw an input beyond the f16 range (its outputs are invalid: re-run it with
   // HCF_PRECISION_EXACT); 0: none. Waits for the passes enqueued so far.
-  int check_range(int* overflowed) {
+  int check_range(int* overflowed, uint32_t* sample_slots = nullptr) {
     if (overflowed) *overflowed = 0;
+    if (sample_slots) *sample_slots = 0;
     if (ovf_latch() != HCF_OK) return rc;
     if (ovf_sticky) {
       if (overflowed) *overflowed = 1;
+      if (sample_slots) *sample_slots = ovf_slots ? ovf_slots : 0x3fffffffu;
       n_fallbacks++;
       ovf_sticky = false;
+      ovf_slots = 0;
     }
     return HCF_OK;
   }
@@ -1501,12 +1504,14 @@ struct hcf_engine {
     ovf_pending = false;
     if (*ovf_host) {
       ovf_sticky = true;
+      ovf_slots |= ((uint32_t)*ovf_host >> 1) & 0x3fffffffu;     // bit 1 + (sample mod 30) of the device flag (hcf_conv_f16x3.hip)
       *ovf_host = 0;
       ovf_clear = true;
     }
     return HCF_OK;
   }
   bool ovf_sticky = false, ovf_clear = false;
+  uint32_t ovf_slots = 0;
   uint32_t pass_flags = 0;
 };
 
@@ -1647,6 +1652,16 @@ int hcf_check_range(hcf_engine* e, int32_t* overflowed) {
   int o = 0;
   const int r = e->check_range(&o);
   if (overflowed) *overflowed = o;
+  return r;
+}
+
+int hcf_check_range_samples(hcf_engine* e, int32_t* overflowed, uint32_t* sample_slots) {
+  if (!e) return HCF_ERR_ARG;
+  int o = 0;
+  uint32_t m = 0;
+  const int r = e->check_range(&o, &m);
+  if (overflowed) *overflowed = o;
+  if (sample_slots) *sample_slots = m;
   return r;
 }
 

@@ -105,6 +105,32 @@ def test_range_overflow_is_rerun_exactly_in_sync_mode_and_reported_in_lazy_mode(
         net.set_range_check("sync")
 
 
+def test_range_overflow_of_one_sample_reruns_that_sample_only():
+    """hcf_check_range_samples: the range flag carries the sample whose tiles saw the overflow; the module (sync policy) redoes
+    exactly that sample on the exact kernels (B = 1, its global sample index for the device draws) and leaves the others'
+    f16x3 results alone -- with injected eps and with device draws."""
+    from hcflow_amd.config import eps_shapes
+    cfg, net = _net("SR_4X_tiny", 11, "f16x3")
+    g = torch.Generator().manual_seed(6)
+    clean = torch.rand(3, 3, 12, 20, generator=g)
+    bad = clean.clone()
+    bad[1, 2, 5, 7] = 9.0e4
+    eps = [torch.randn(s, generator=g) * 0.5 for s in eps_shapes(cfg, 3, 12, 20)]
+    with torch.no_grad():
+        for kw in (dict(seed=3), dict(eps=eps)):
+            ref_clean = net(lr=clean.cuda(), eps_std=0.5, reverse=True, **kw)
+            n0 = net.engine().fallback_count()
+            out = net(lr=bad.cuda(), eps_std=0.5, reverse=True, **kw)
+            assert net.engine().fallback_count() == n0 + 1
+            net.set_precision("exact")
+            ex = net(lr=bad.cuda(), eps_std=0.5, reverse=True, **kw)
+            net.set_precision("f16x3")
+            assert torch.equal(out[1].view(torch.int32), ex[1].view(torch.int32))
+            assert torch.equal(out[0], ref_clean[0]) and torch.equal(out[2], ref_clean[2])
+            ok, slots = net.engine().check_range_samples()
+            assert not ok and slots == 0
+
+
 @pytest.mark.parametrize("precision", ["exact", "f16x3"])
 def test_steady_state_inverse_only_enqueues_and_can_be_graph_captured(precision):
     """With the plan cached and the range flag read back asynchronously a steady-state call contains no allocation and no

@@ -182,25 +182,46 @@ def test_config4_shard_b8_vs_cpu_oracle():
         net.set_precision("exact")
 
 
-def test_config2_forced_range_fallback_returns_the_exact_kernels_bits():
+def test_config2_forced_range_fallback_reruns_only_the_affected_sample():
     """BASELINE config 2 (full depth, B = 16, LR 160x160, tau 0.8) with ONE activation beyond the f16 range: the default policy
-    ("sync") re-runs the whole pass on the exact fp32-MFMA kernels before the call returns -- the output is bit-identical to
-    set_precision("exact") and the fallback is counted (the 117 -> 36 img/s cliff documented in INTEGRATION.md)."""
+    ("sync") re-runs the AFFECTED SAMPLE on the exact fp32-MFMA kernels before the call returns (every op of the path is
+    per-sample, HCFlowNet_SR_arch.py:70-75; include/hcflow.h: hcf_check_range_samples) -- that sample's output is bit-identical to
+    set_precision("exact"), the other fifteen keep the bits of a clean f16x3 pass, one fallback is counted, and the call costs
+    about one B = 1 exact pass more than a clean one (not the 3.4x of a whole-batch exact re-run)."""
     cfg, p, net = _net("SR_DF2K_4X", 1234)
     g = torch.Generator().manual_seed(1600)
-    lr = torch.rand(16, 3, 160, 160, generator=g)
+    lr_clean = torch.rand(16, 3, 160, 160, generator=g)
+    lr = lr_clean.clone()
     lr[5, 1, 77, 90] = 7.0e4                            # > 65504: not representable by the f16 hi part
-    lr = lr.cuda()
+    lr, lr_clean = lr.cuda(), lr_clean.cuda()
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
     try:
         with torch.no_grad():
             net.set_precision("f16x3").set_range_check("sync")
+            t_clean, clean = timed(lambda: net(lr=lr_clean, z=None, u=None, eps_std=0.8, reverse=True, seed=99))
             n0 = net.engine().fallback_count()
             fb = net(lr=lr, z=None, u=None, eps_std=0.8, reverse=True, seed=99)
             assert net.engine().fallback_count() == n0 + 1
+            t_fb, fb2 = timed(lambda: net(lr=lr, z=None, u=None, eps_std=0.8, reverse=True, seed=99))
+            assert torch.equal(fb, fb2)
             net.set_precision("exact")
             ex = net(lr=lr, z=None, u=None, eps_std=0.8, reverse=True, seed=99)
-            assert torch.allclose(fb, ex, rtol=0, atol=0, equal_nan=True)
-            # samples that never saw the outlier are finite and untouched by it (per-sample ops)
-            assert bool(torch.isfinite(fb[:5]).all()) and bool(torch.isfinite(fb[6:]).all())
+            assert torch.allclose(fb[5], ex[5], rtol=0, atol=0, equal_nan=True)          # the affected sample: the exact kernels' bits
+            rest = [b for b in range(16) if b != 5]
+            assert torch.equal(fb[rest], clean[rest])                                    # untouched: a clean f16x3 pass' bits
+            assert bool(torch.isfinite(fb[rest]).all())
+            assert float((fb[rest] - ex[rest]).abs().max()) <= 1e-4
+            print("forced fallback: clean %.1f ms, with one out-of-range sample %.1f ms (x%.2f)" % (t_clean, t_fb, t_fb / t_clean))
+            assert t_fb <= 1.35 * t_clean, (t_fb, t_clean)
     finally:
         net.set_precision("exact")
