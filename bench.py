@@ -173,10 +173,30 @@ def main():
             out = gathered_step(net, lr, args.tau, 4242 + it, out_all, overlap=True)   # this rank's shard + async RCCL all-gather (N > 1)
         return out
 
+    class Engines:
+        """The module's engines of this GPU as one (a split call runs its two half batches on two engines / HIP streams): the
+        conv records of both are summed (each launch is timed with HIP events on ITS stream)."""
+        def _all(self):
+            return net.engines()
+
+        def profile_convs(self, on):
+            for e in self._all():
+                e.profile_convs(on)
+
+        def conv_time(self, *a, **kw):
+            rows = [e.conv_time(*a, **kw) for e in self._all()]
+            return tuple(sum(r[i] for r in rows) for i in range(4))
+
+        def workspace_bytes(self):
+            return sum(e.workspace_bytes() for e in self._all())
+
+        def weight_bytes(self):
+            return sum(e.weight_bytes() for e in self._all())
+
     def timed(mode, warmup, steps):
         """`steps` timed steps of `mode` between barrier + synchronize pairs; conv launches timed with HIP events on the stream."""
         net.set_precision(mode)
-        eng = net.engine()
+        eng = Engines()
         with torch.no_grad():
             for i in range(warmup):
                 step(i)
@@ -299,7 +319,7 @@ def main():
     overflow = net.check_range()                        # the one wait for the asynchronous range flag
     if check is not None:
         check["range_overflow_in_any_pass"] = bool(overflow)
-    eng = net.engine()
+    eng = Engines()
 
     if rank == 0:
         img_s = world * B * args.steps / dt
@@ -332,6 +352,9 @@ def main():
                                    % (args.preset, "forward -> Quant -> inverse round trip" if roundtrip else
                                       "inverse sampling (netG reverse=True)", B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
                        "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
+                       "streams_per_gpu": (2 if net._nstreams[0] >= 2 and B >= 4 else 1),
+                       "streams_note": "module default: a call of >= 4 samples runs as two half batches on two HIP streams of the GPU "
+                                       "(two engines; HCFLOW_STREAMS=1 = one stream); conv launches of both streams are in `roofline`",
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
             "precision": {"mode": default_mode, "is_module_default": default_mode == "f16x3",

@@ -415,6 +415,33 @@ class _EngineModule(nn.Module):
         # check_range() (the calls only enqueue: CUDA-graph capturable); "off" skips the read-back altogether.
         object.__setattr__(self, "_range_check", [os.environ.get("HCFLOW_RANGE_CHECK", "sync")])
         object.__setattr__(self, "_cond_key", {})
+        # Inference calls of >= 4 samples run as TWO half batches on two HIP streams of the GPU (two engines): every op of the path
+        # is per-sample, the convolutions are persistent one-block-per-CU launches, and the second stream's kernels fill the
+        # ragged last rounds and launch boundaries of the first's (config 2: +3.6 %, Face x8 B = 32: +25 %, profiles/r05_notes.md).
+        # HCFLOW_STREAMS=1 (or set_streams(1)) keeps every call on the caller's stream.
+        object.__setattr__(self, "_nstreams", [max(1, min(2, int(os.environ.get("HCFLOW_STREAMS", "2"))))])
+        object.__setattr__(self, "_side_streams", {})
+
+    def set_streams(self, n: int):
+        """1: every call runs on the caller's stream with one engine; 2 (default): inference calls of >= 4 samples are split
+        into two half batches that run side by side on two streams (joined before the call returns)."""
+        assert n in (1, 2), n
+        self._nstreams[0] = int(n)
+        return self
+
+    def _side_stream(self, idx):
+        st = self._side_streams.get(idx)
+        if st is None:
+            st = torch.cuda.Stream(device=idx)
+            self._side_streams[idx] = st
+        return st
+
+    def engines(self):
+        """Every live engine of this module's device (the primary and, once a split call has run, its twin)."""
+        dev = self._device()
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._engine_for(dev)
+        return [ent["engine"] for k, ent in self._engines.items() if k == idx or (isinstance(k, tuple) and k[0] == idx)]
 
     def set_range_check(self, mode: str):
         assert mode in ("sync", "lazy", "off"), mode
@@ -492,17 +519,20 @@ class _EngineModule(nn.Module):
         return self
 
     # -- engine management
-    def _engine_for(self, device: torch.device):
+    def _engine_for(self, device: torch.device, slot: int = 0):
+        """The engine of ``device`` (slot 0), or its twin (slot 1: the second half batch of a split inference call runs on it,
+        beside slot 0's, on a second HIP stream -- its own workspace and packs, the same parameter tensors)."""
         if device.type != "cuda":
             raise _lib.HcfError(
                 "hcflow_amd runs on MI355X only: move the module and its inputs to a GPU "
                 "(module parameters are on %s). There is no CPU fallback." % device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ent = self._engines.get(idx)
+        key = idx if slot == 0 else (idx, slot)
+        ent = self._engines.get(key)
         if ent is None:
             ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
             ent["engine"].set_precision(self._precision[0])
-            self._engines[idx] = ent
+            self._engines[key] = ent
         named = self._tensors()
         stamp = tuple((p.data_ptr(), p._version) for _, p in named)
         if ent["stamp"] != stamp:
@@ -548,28 +578,56 @@ class _EngineModule(nn.Module):
     def _params(self):
         return [p for _, p in self._tensors()]
 
-    def _run_checked(self, eng, idx, call, what, batch=0, call_sample=None):
-        """One inference pass through the C ABI (``call()`` enqueues it and returns the status) under the range-check policy.
-        ``call_sample(b)`` (optional) enqueues the pass for sample ``b`` of the batch alone: every op of the path is per-sample
+    def _run_checked(self, eng, idx, call, what, batch=0, call_sample=None, parts=None):
+        """One inference pass through the C ABI under the range-check policy. ``call(eng, lo, hi, stream)`` enqueues samples
+        [lo, hi) on ``eng`` and returns the status. ``parts`` (optional): [(engine, lo, hi, torch stream or None)] -- the split of a
+        batch over the device's engines / streams (None = the caller's stream); the side streams are joined before returning.
+        ``call_sample(b)`` (optional) enqueues sample ``b`` alone on ``eng``: every op of the path is per-sample
         (HCFlowNet_SR_arch.py:70-75), so an activation beyond the f16 range costs an exact re-run of the samples whose tiles saw
         it (B = 1 passes on the fp32-MFMA kernels into the same output rows), not of the whole batch."""
         with torch.cuda.device(idx):
-            _lib.check(call(), eng.handle, what)
+            cur = torch.cuda.current_stream(idx)
+            if parts is None:
+                parts = [(eng, 0, batch, None)]
+            for e_, lo, hi, st_ in parts:
+                if st_ is None:
+                    _lib.check(call(e_, lo, hi, C.c_void_p(cur.cuda_stream)), e_.handle, what)
+                else:
+                    st_.wait_stream(cur)                          # the inputs were produced on the caller's stream
+                    with torch.cuda.stream(st_):
+                        _lib.check(call(e_, lo, hi, C.c_void_p(st_.cuda_stream)), e_.handle, what)
+            for _, _, _, st_ in parts:
+                if st_ is not None:
+                    cur.wait_stream(st_)                          # joined: the output is complete on the caller's stream
             if self._precision[0] != "f16x3" or self._range_check[0] != "sync":
                 return
-            over, slots = eng.check_range_samples()
-            if not over:
+            flagged, any_over = [], False
+            for e_, lo, hi, _ in parts:
+                over, slots = e_.check_range_samples()
+                any_over = any_over or over
+                if over:
+                    flagged += [lo + b for b in range(hi - lo) if (slots >> (b % 30)) & 1]
+            if not any_over:
                 return
-            flagged = [b for b in range(batch) if (slots >> (b % 30)) & 1]
             eng.set_precision("exact")                       # an activation left the f16 range: redo exactly
             try:
-                if call_sample is not None and 0 < len(flagged) < batch:
+                # (a lone sample runs the exact kernels at a fraction of their batch throughput: beyond half the batch the whole
+                #  pass is the cheaper re-run)
+                if call_sample is not None and 0 < len(flagged) <= max(1, batch // 2):
                     for b in flagged:
                         _lib.check(call_sample(b), eng.handle, what + " (exact re-run of sample %d)" % b)
                 else:
-                    _lib.check(call(), eng.handle, what + " (exact re-run)")
+                    _lib.check(call(eng, 0, batch, C.c_void_p(cur.cuda_stream)), eng.handle, what + " (exact re-run)")
             finally:
                 eng.set_precision(self._precision[0])
+
+    def _parts(self, dev, idx, eng, B, allow=True):
+        """How a batch of B samples is spread over the device's engines / streams."""
+        if not allow or self._nstreams[0] < 2 or B < 4:
+            return None
+        eng2, _ = self._engine_for(dev, slot=1)
+        h1 = B - B // 2
+        return [(eng, 0, h1, None), (eng2, h1, B, self._side_stream(idx))]
 
     def _check_inference(self, reverse=False):
         if self._wants_grad():
@@ -717,20 +775,24 @@ class _EngineModule(nn.Module):
             self._cond_key[idx] = (key, lr_in)
         else:
             self._cond_key.pop(idx, None)
-        stream = self._stream(idx)
+        def arr_for(lo, hi):
+            if lo == 0 and hi == B:
+                return arr
+            a_ = (C.c_void_p * len(shapes))()
+            for i, e in enumerate(keep_at):
+                a_[i] = None if e is None else e[lo:hi].data_ptr()     # contiguous NCHW row slices, no copies
+            return a_
+
+        def run(eng_, lo, hi, stream_, fl=flags):
+            # samples [lo, hi): their LR rows, their rows of the injected draws (or the same seed with their global sample index:
+            # the device draws are indexed by sample, hcf_inverse_ex), their output rows
+            return eng_.lib.hcf_inverse_ex(eng_.handle, lr[lo:hi].data_ptr(), arr_for(lo, hi), len(shapes), tau, seed,
+                                           int(sample_offset) + lo, out[lo:hi].data_ptr(), hi - lo, h, w, fl, stream_)
 
         def one_sample(b):
-            # sample b alone: its LR row, its rows of the injected draws (or the same seed with its global sample index: the
-            # device draws are indexed by sample, hcf_inverse_ex), its output row; contiguous NCHW slices, no copies
-            arr1 = (C.c_void_p * len(shapes))()
-            for i, e in enumerate(keep_at):
-                arr1[i] = None if e is None else e[b:b + 1].data_ptr()
-            return eng.lib.hcf_inverse_ex(eng.handle, lr[b:b + 1].data_ptr(), arr1, len(shapes), tau, seed, int(sample_offset) + b,
-                                          out[b:b + 1].data_ptr(), 1, h, w, flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND),
-                                          stream)
-        self._run_checked(eng, idx, lambda: eng.lib.hcf_inverse_ex(
-            eng.handle, lr.data_ptr(), arr, len(shapes), tau, seed, int(sample_offset), out.data_ptr(), B, h, w, flags,
-            stream), "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample)
+            return run(eng, b, b + 1, self._stream(idx), flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND))
+        self._run_checked(eng, idx, run, "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample,
+                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond))
         return out
 
     # convenience for benchmarks / multi-GPU sharding
@@ -779,10 +841,10 @@ class HCFlowNet_SR(_EngineModule):
         logdet = torch.empty(B, device=dev)
         zraw = torch.empty(B, 3, H // s, W // s, device=dev) if return_internals else None
         pend = self._arm_actnorm_init(eng)
-        stream = self._stream(idx)
-        self._run_checked(eng, idx, lambda: eng.lib.hcf_forward_sr(
-            eng.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(), noise.data_ptr(), out_lr.data_ptr(),
-            nll.data_ptr(), logdet.data_ptr(), None if zraw is None else zraw.data_ptr(), B, H, W, stream), "hcf_forward_sr")
+        self._run_checked(eng, idx, lambda e_, lo, hi, stream: e_.lib.hcf_forward_sr(
+            e_.handle, hr.data_ptr(), None if lr_t is None else lr_t.data_ptr(), noise.data_ptr(), out_lr.data_ptr(),
+            nll.data_ptr(), logdet.data_ptr(), None if zraw is None else zraw.data_ptr(), B, H, W, stream), "hcf_forward_sr",
+            batch=B)                       # (the NLL is a mean over the batch: one pass, one stream)
         self._finish_actnorm_init(eng, idx, pend)
         if return_internals:
             return out_lr, nll[0], logdet, zraw
@@ -848,11 +910,10 @@ class HCFlowNet_Rescaling(_EngineModule):
         z1 = torch.empty(B, c0, H // 2, W // 2, device=dev)
         z2 = torch.empty(B, c1, H // 4, W // 4, device=dev)
         pend = self._arm_actnorm_init(eng)
-        stream = self._stream(idx)
         fl = (0 if clamp else _lib.FLAG_NO_CLAMP) | (_lib.FLAG_NO_RANGE_CHECK if self._range_check[0] == "off" else 0)
-        self._run_checked(eng, idx, lambda: eng.lib.hcf_forward_rescale(
-            eng.handle, hr.data_ptr(), out_lr.data_ptr(), z1.data_ptr(), z2.data_ptr(), B, H, W, fl, stream),
-            "hcf_forward_rescale")
+        self._run_checked(eng, idx, lambda e_, lo, hi, stream: e_.lib.hcf_forward_rescale(
+            e_.handle, hr[lo:hi].data_ptr(), out_lr[lo:hi].data_ptr(), z1[lo:hi].data_ptr(), z2[lo:hi].data_ptr(), hi - lo, H, W,
+            fl, stream), "hcf_forward_rescale", batch=B, parts=self._parts(dev, idx, eng, B, allow=not pend))
         self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 

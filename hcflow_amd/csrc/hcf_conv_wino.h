@@ -74,6 +74,7 @@ struct Args {
   const float* f_bias; const float* f_scale; int f_act;
   int* ovf;
   const char* zeros;       // >= 64 bytes of zeros
+  int top_wait;            // A/B knob (HCF_WINO_TOP_WAIT=1): the 64-channel kernel waits at the top of every unit's first chunk as before round 5
   unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
 };
 
@@ -671,7 +672,12 @@ __device__ __forceinline__ void wino64_epilogue(const Args& a, char* const lds, 
           if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
         }
         if (F1) hv[nt][oa][ob] = v;
-        else if (oks[oa][ob] && cb < a.cout) {
+        else {
+          if (nt == 0 && oa == 0 && ob == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of this wave (the next
+                                                    // unit's first chunk included) has landed BEFORE the unit's first store is issued:
+                                                    // the next chunk's top does not wait again (conv_wino4_kernel)
+        }
+        if (!F1 && oks[oa][ob] && cb < a.cout) {
           if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pixs[oa][ob] * a.out2_cs + a.out2_c0 + (cb - 32)) = v;
           else *reinterpret_cast<f32x4*>(a.out + pixs[oa][ob] * a.out_cs + a.out_c0 + cb) = v;
         }
@@ -725,6 +731,7 @@ __device__ __forceinline__ void wino64_epilogue(const Args& a, char* const lds, 
       }
     }
     const int xx = ex0 + li;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (as above: before the unit's first store)
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int yy = ey0 + r0 + rr;
@@ -909,7 +916,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #if defined(WINO_PROF)
       const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (the first chunk of a LATER unit: its image, weights and fragments were requested during the previous unit's last chunk and
+      //  waited for inside that unit's epilogue, before its first global store -- vmcnt counts stores too, and a wait here would
+      //  sit out the epilogue's store acknowledgements, ~1 500 cycles per unit)
+      if (c > 0 || g == 0 || a.top_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if defined(WINO_PROF)
       const unsigned long long q1 = __builtin_readcyclecounter();
 #endif

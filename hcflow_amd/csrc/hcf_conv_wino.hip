@@ -148,6 +148,8 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   }
   w.ovf = a.ovf;
   w.zeros = reinterpret_cast<const char*>(a.zeros);
+  static const int top_wait = getenv("HCF_WINO_TOP_WAIT") ? atoi(getenv("HCF_WINO_TOP_WAIT")) : 0;     // A/B knob, read once
+  w.top_wait = top_wait;
   const int ncu = wino_ncu();
   // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of

@@ -29,12 +29,15 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--ways", type=int, default=2)
+    ap.add_argument("--preset", default="SR_DF2K_4X")
+    ap.add_argument("--lr-size", type=int, default=160)
+    ap.add_argument("--threads", type=int, default=1, help="1: ONE host thread enqueues the streams in turn (what a module would do); 0: a thread per stream")
     args = ap.parse_args()
-    cfg = preset("SR_DF2K_4X")
+    cfg = preset(args.preset)
     params = make_params(cfg, 1234)
     nets = [build(cfg, params) for _ in range(args.ways)]
     B = args.batch
-    lr = torch.rand(B, 3, 160, 160).cuda()
+    lr = torch.rand(B, 3, args.lr_size, args.lr_size).cuda()
     with torch.no_grad():
         for n in nets:
             n(lr=lr[:B // args.ways], eps_std=0.8, reverse=True)
@@ -55,9 +58,17 @@ def main():
 
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(i,)) for i in range(args.ways)]
-        [t.start() for t in th]
-        [t.join() for t in th]
+        if args.threads == 0:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(args.ways)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        else:
+            for n in nets:
+                n.set_range_check("lazy")
+            for _ in range(args.steps):
+                for i in range(args.ways):
+                    with torch.cuda.stream(streams[i]):
+                        nets[i](lr=parts[i], eps_std=0.8, reverse=True)
         torch.cuda.synchronize()
         two = (time.perf_counter() - t0) / args.steps
     print("one stream, B=%d: %.1f ms/step = %.1f img/s;  %d streams x B=%d: %.1f ms/step = %.1f img/s  (%+.1f %%)" % (
