@@ -353,8 +353,8 @@ def main():
                                       "inverse sampling (netG reverse=True)", B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
                        "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
                        "streams_per_gpu": (2 if net._nstreams[0] >= 2 and B >= 4 else 1),
-                       "streams_note": "module default: a call of >= 4 samples runs as two half batches on two HIP streams of the GPU "
-                                       "(two engines; HCFLOW_STREAMS=1 = one stream); conv launches of both streams are in `roofline`",
+                       "streams_note": "module default 1; HCFLOW_STREAMS=2 runs a call of >= 4 samples as two half batches on two HIP "
+                                       "streams (opt-in: +2.8 % here, but overlapping kernels void the per-kernel roofline bookkeeping)",
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
             "precision": {"mode": default_mode, "is_module_default": default_mode == "f16x3",

@@ -415,16 +415,19 @@ class _EngineModule(nn.Module):
         # check_range() (the calls only enqueue: CUDA-graph capturable); "off" skips the read-back altogether.
         object.__setattr__(self, "_range_check", [os.environ.get("HCFLOW_RANGE_CHECK", "sync")])
         object.__setattr__(self, "_cond_key", {})
-        # Inference calls of >= 4 samples run as TWO half batches on two HIP streams of the GPU (two engines): every op of the path
-        # is per-sample, the convolutions are persistent one-block-per-CU launches, and the second stream's kernels fill the
-        # ragged last rounds and launch boundaries of the first's (config 2: +3.6 %, Face x8 B = 32: +25 %, profiles/r05_notes.md).
-        # HCFLOW_STREAMS=1 (or set_streams(1)) keeps every call on the caller's stream.
-        object.__setattr__(self, "_nstreams", [max(1, min(2, int(os.environ.get("HCFLOW_STREAMS", "2"))))])
+        # OPT-IN (HCFLOW_STREAMS=2 or set_streams(2)): inference calls of >= 4 samples run as TWO half batches on two HIP streams of
+        # the GPU (two engines): every op of the path is per-sample, the convolutions are persistent one-block-per-CU launches,
+        # and the second stream's kernels fill the ragged last rounds and launch boundaries of the first's. Measured same-box
+        # (profiles/r05_notes.md section 4): config 2 +2.8 %, config 4 +6..12 %, Face x8 +-0; NOT the default because (i) the
+        # kernels of the two streams overlap, so per-kernel durations (HIP events, rocprofv3) no longer add up to the step and the
+        # roofline bookkeeping of bench.py loses its meaning, and (ii) a process that also trains runs out of hardware queues
+        # (HIP maps streams onto 4 of them: the training pass' weight-gradient stream then shares one with its dependency chain).
+        object.__setattr__(self, "_nstreams", [max(1, min(2, int(os.environ.get("HCFLOW_STREAMS", "1"))))])
         object.__setattr__(self, "_side_streams", {})
 
     def set_streams(self, n: int):
-        """1: every call runs on the caller's stream with one engine; 2 (default): inference calls of >= 4 samples are split
-        into two half batches that run side by side on two streams (joined before the call returns)."""
+        """1 (default): every call runs on the caller's stream with one engine; 2: inference calls of >= 4 samples are split
+        into two half batches that run side by side on two side streams (joined before the call returns)."""
         assert n in (1, 2), n
         self._nstreams[0] = int(n)
         return self
@@ -432,7 +435,7 @@ class _EngineModule(nn.Module):
     def _side_stream(self, idx):
         st = self._side_streams.get(idx)
         if st is None:
-            st = torch.cuda.Stream(device=idx)
+            st = torch.cuda.Stream(device=idx[0] if isinstance(idx, tuple) else idx)
             self._side_streams[idx] = st
         return st
 
@@ -627,7 +630,9 @@ class _EngineModule(nn.Module):
             return None
         eng2, _ = self._engine_for(dev, slot=1)
         h1 = B - B // 2
-        return [(eng, 0, h1, None), (eng2, h1, B, self._side_stream(idx))]
+        # NEITHER half on the caller's stream: that is normally the process' default (null) stream, whose launches do not run beside
+        # another stream's (measured: the halves serialise, 140 against 130 ms per step; on two side streams they overlap)
+        return [(eng, 0, h1, self._side_stream((idx, 0))), (eng2, h1, B, self._side_stream((idx, 1)))]
 
     def _check_inference(self, reverse=False):
         if self._wants_grad():

@@ -105,6 +105,46 @@ def test_range_overflow_is_rerun_exactly_in_sync_mode_and_reported_in_lazy_mode(
         net.set_range_check("sync")
 
 
+@pytest.mark.parametrize("name", ["SR_4X_tiny", "Rescaling_4X_tiny"])
+def test_two_stream_split_equals_the_single_stream_call(name):
+    """set_streams(2) (opt-in): a call of >= 4 samples runs as two half batches on two side streams / two engines, joined before it
+    returns. Every op is per-sample and the device draws are indexed by the global sample, so the outputs equal the one-stream
+    call's bit for bit (tiny nets: same kernel schedule at every batch size) -- sampling path, injected eps, the rescaling
+    forward, and the per-sample range fallback across the two halves."""
+    from hcflow_amd.config import eps_shapes
+    cfg, net = _net(name, 11, "f16x3")
+    g = torch.Generator().manual_seed(8)
+    lr = torch.rand(6, 3, 12, 16, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.6 for s in eps_shapes(cfg, 6, 12, 16)]
+    with torch.no_grad():
+        one = [net(lr=lr, eps_std=0.6, reverse=True, seed=21), net(lr=lr, eps_std=0.6, reverse=True, eps=eps)]
+        net.set_streams(2)
+        try:
+            two = [net(lr=lr, eps_std=0.6, reverse=True, seed=21), net(lr=lr, eps_std=0.6, reverse=True, eps=eps)]
+            assert len(net.engines()) == 2
+            assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1])
+            if not cfg.sr:
+                hr = torch.rand(6, 3, 48, 64, generator=g).cuda()
+                net.set_streams(1)
+                a = net(hr=hr, reverse=False)
+                net.set_streams(2)
+                b = net(hr=hr, reverse=False)
+                assert all(torch.equal(x, y) for x, y in zip(a, b))
+            bad = lr.clone()
+            bad[4, 0, 3, 3] = 9.0e4                           # second half (samples 3..5): flagged by the twin engine
+            n0 = sum(e.fallback_count() for e in net.engines())
+            out = net(lr=bad, eps_std=0.6, reverse=True, seed=21)
+            assert sum(e.fallback_count() for e in net.engines()) == n0 + 1
+            net.set_precision("exact")
+            ex = net(lr=bad, eps_std=0.6, reverse=True, seed=21)
+            net.set_precision("f16x3")
+            assert torch.equal(out[4].view(torch.int32), ex[4].view(torch.int32))
+            rest = [0, 1, 2, 3, 5]
+            assert torch.equal(out[rest], two[0][rest])
+        finally:
+            net.set_streams(1)
+
+
 def test_range_overflow_of_one_sample_reruns_that_sample_only():
     """hcf_check_range_samples: the range flag carries the sample whose tiles saw the overflow; the module (sync policy) redoes
     exactly that sample on the exact kernels (B = 1, its global sample index for the device draws) and leaves the others'
