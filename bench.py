@@ -438,6 +438,10 @@ def train_workload(args, dev, world, rank):
                                                    "backward_incl_allreduce": round(1e3 * (t2 - t1), 2),
                                                    "clip_adam": round(1e3 * (t3 - t2), 2)},
                "mfma_frac": round(B * args.steps / dt * GFLOP_TRAIN_SAMPLE / 1e3 / peak, 4),
+               # per phase (synchronised step): forward = 184.27 GFLOP per sample (incl. the per-step pack refresh in its time),
+               # backward = data + weight gradients = 2x that
+               "mfma_frac_forward": round(B * (GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / (t1 - t0) / peak, 4),
+               "mfma_frac_backward": round(B * (2.0 * GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / (t2 - t1) / peak, 4),
                "allreduce_MB_per_step": round(grad_allreduce_bytes(net) / 1e6, 1) if world > 1 else 0.0,
                "activation_arena_GB": round(net.engine().workspace_bytes() / 2 ** 30, 2)}
         del opt
@@ -590,7 +594,11 @@ def other_configs(dev, params_sr4, steps, mode):
             "phases_ms": {"forward_incl_refresh": round(1e3 * med[0], 2), "backward": round(1e3 * med[1], 2),
                           "clip_adam": round(1e3 * med[2], 2)},
             "steps_ms": [round(1e3 * sum(r), 2) for r in rows], "statistic": "median of %d timed steps after 2 warm-up steps" % tsteps,
-            "mfma_frac": round(16 * GFLOP_TRAIN_SAMPLE / 1e3 / dt / peak, 4)}
+            "mfma_frac": round(16 * GFLOP_TRAIN_SAMPLE / 1e3 / dt / peak, 4),
+            "mfma_frac_forward": round(16 * (GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / med[0] / peak, 4),
+            "mfma_frac_backward": round(16 * (2.0 * GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / med[1] / peak, 4),
+            "note": "phases are host-synchronised (sum of the three); the free-running step of train_HCFlow.py's loop overlaps the "
+                    "optimiser's host work with the backward pass on the GPU: `python bench.py --workload train` times that"}
     out["config5_nll_train_step"] = train_config(False)
     out["config5_nll_train_step"]["optimizer"] = "torch.optim.Adam + torch.nn.utils.clip_grad_norm_ (the reference caller's lines, unchanged)"
     try:

@@ -132,9 +132,15 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // (a.in_max, device) before the split and the accumulators are scaled back in the epilogue: gradients of 1e-8 would
 // otherwise fall below the f16 split's absolute floor (a_lo is unscaled).
 // K1 (training: the FCNs' stand-alone 1x1 conv2 and its data gradient; the inference passes run it fused, FUSE2): one tap, no halo.
-template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false, bool K1 = false>
+// N16 (round 5; fused-tail variants with <= 16 output channels: the Conv2dZeros of the 6- and 12-channel flow steps, whose 32-wide
+// channel tile was 62 / 81 % zero padding): the products run on v_mfma_f32_16x16x32_f16 -- M = 16 pixels, N = 16 channels, K = 32 =
+// [16 hi | 16 lo] of one chunk: ONE instruction forms a_hi b_hi + a_lo b_hi (B = [b_hi ; b_hi]), a second one a_hi b_lo
+// (B = [b_lo ; 0]) -- 2/3 of the matrix work of the 32-wide tile (4 half-size MFMAs per 32 pixels and tap instead of 3 full-size
+// ones), same pack, same LDS images.
+template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false, bool K1 = false, bool N16 = false>
 __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
+  static_assert(!N16 || (NTB == 1 && TAILC > 0 && (TH == 8 || TH == 4)), "the 16-wide channel tile is built for the fused-tail variants");
   static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
   static_assert(TH == 8 || TH == 4 || (!FUSE2 && TAILC == 0), "the fused epilogues are sized for the 8- and 4-row tiles");
   static_assert(TH == 4 || TH == 8 || TH == 16, "tile heights");
@@ -338,11 +344,19 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
   }
 #endif
 
-  f32x16 acc[MT];
+  f32x16 acc[N16 ? 1 : MT];
+  f32x4 acc16[N16 ? MT : 1][2];                     // N16: [tile row][16-pixel half]; lane = (channel l & 15, pixels 4 (l >> 4) .. + 3)
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < (N16 ? 1 : MT); ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < (N16 ? MT : 1); ++m)
+#pragma unroll
+    for (int hr = 0; hr < 2; ++hr) acc16[m][hr] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l16 = lane & 15, kg = lane >> 4;        // N16 fragment coordinates: row / column l16, K group kg (8 halves each)
+  const int abase16 = ((MT * wm) * HW + l16) * REC + kg * 16;          // record = [16 hi | 16 lo]: K groups 0, 1 = hi, 2, 3 = lo
+  const int bbase16 = (kg & 1) * BHALF + l16 * 16;
 
   const int nchunk = a.nchunk;
   for (int c = 0; c < nchunk; ++c) {
@@ -350,6 +364,30 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
     if (more) HCF_STAGE_LOAD(c + 1);               // global loads fly under this chunk's MFMAs
     __builtin_amdgcn_sched_barrier(0);             // keep them here (the scheduler would sink them to the split)
     __builtin_amdgcn_s_setprio(1);                 // MFMA phase outranks the other blocks' staging phases on this SIMD (+2 %)
+    if constexpr (N16) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int dy = t / 3, dx = t % 3;
+        const char* bt = ldsB + bbase16 + t * (4 * BHALF);
+        const f16x8 b1 = *reinterpret_cast<const f16x8*>(bt);             // [b_hi k-half (kg & 1)]: multiplies a_hi (kg 0, 1) and a_lo (kg 2, 3)
+        f16x8 b2 = *reinterpret_cast<const f16x8*>(bt + 2 * BHALF);       // [b_lo k-half] for a_hi; the a_lo x b_lo term is dropped
+        if (kg >= 2) b2 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        f16x8 af[MT][2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr)
+            af[m][hr] = *reinterpret_cast<const f16x8*>(lds + abase16 + ((m + dy) * HW + dx + 16 * hr) * REC);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) acc16[m][hr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][hr], b1, acc16[m][hr], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) acc16[m][hr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m][hr], b2, acc16[m][hr], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int dy = t / 3, dx = t % 3;
@@ -421,9 +459,17 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
   // cheaper than testing every staged element of every chunk.
   float chk = 0.f;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < (N16 ? 1 : MT); ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) chk = fmaf(acc[m][r], 0.f, chk);   // stays 0 unless some acc is inf / NaN
+  if constexpr (N16) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) chk = fmaf(acc16[m][hr][j], 0.f, chk);
+  }
 
   if constexpr (FUSE2) {
     // layer 1 epilogue -> split f16 A operand in LDS: record (px, kc) = [16 hi | 16 lo] halves of channels 16kc..16kc+15
@@ -486,8 +532,22 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
 
   if constexpr (TAILC > 0) {
     float* hl = reinterpret_cast<float*>(lds);
-    const float bias_t = a.bias[oc], scale_t = a.scale[oc];
     __syncthreads();                                 // every wave is done with the staging buffers
+    if constexpr (N16) {
+      const float bias_t = a.bias[l16], scale_t = a.scale[l16];
+      if (l16 < cout) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int px = (MT * wm + m) * TW + 16 * hr + 4 * kg + j;
+              hl[px * HCS + l16] = (acc16[m][hr][j] * UNSPLIT + bias_t) * scale_t;
+            }
+      }
+    } else {
+    const float bias_t = a.bias[oc], scale_t = a.scale[oc];
     if (ocok) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -496,6 +556,7 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
           const int px = (MT * wm + m) * TW + (r & 3) + 8 * (r >> 2) + 4 * half;
           hl[px * HCS + oc] = (acc[m][r] * UNSPLIT + bias_t) * scale_t;       // Conv2dZeros: no activation
         }
+    }
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
@@ -684,6 +745,13 @@ static int launch_t(const ConvArgs& a, hipStream_t st) {
     if constexpr (NTB == 1) {
       const long long nblk4 = (long long)a.B * tiles_x * ((a.H + 3) / 4);
       const bool th4 = nblk4 <= 256 && getenv("HCF_NO_TH4") == nullptr;      // small grids: 4-row tiles (see the plain variant below)
+      static const bool n16_off = getenv("HCF_NO_N16") != nullptr;              // A/B knob: the 16-wide channel tile (<= 16 output channels)
+      const bool n16 = a.out.n <= 16 && !n16_off && !(g_f16x3_ablation & 2048);
+      if (n16 && th4 && cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8, 4, false, false, true>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+      else if (n16 && th4 && cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12, 4, false, false, true>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
+      else if (n16 && !th4 && cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8, 8, false, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else if (n16 && !th4 && cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12, 8, false, false, true>), dim3((unsigned)nblk), dim3(256), 0, st, b);
+      else
       if (th4 && cm == 8) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 8, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
       else if (th4 && cm == 12) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 12, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
       else if (th4 && cm == 24) hipLaunchKernelGGL((conv_f16x3_kernel<1, true, false, false, 24, 4>), dim3((unsigned)nblk4), dim3(256), 0, st, b);
