@@ -25,7 +25,9 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from hcflow_amd.config import NetConfig, layer_plan
+import re
+
+from hcflow_amd.config import NetConfig      # the parsed options (yml values) only: the layer structure below is re-derived from the state dict
 
 P = Dict[str, torch.Tensor]
 LOG2PI = float(np.log(2 * np.pi))
@@ -375,7 +377,7 @@ def condflow_forward(a, u, logdet, p: P, pre: str, cfg: NetConfig, level: int):
     """
     cf = cond_features(u, p, pre, cfg)
     z = a
-    for k in range(cfg.after[level]):
+    for k in range(_plan_from_state(p, cfg)[1][level]):
         z, logdet = flowstep_forward(z, cf, logdet, p, "%s.additional_flow_steps.%d" % (pre, k),
                                      cfg.c_perm, cfg.c_coupling, cfg.c_nn_module)
     h = conv_zeros(cf, p, pre + ".f")
@@ -394,13 +396,49 @@ def condflow_inverse(u, p: P, pre: str, cfg: NetConfig, level: int, eps_std, eps
     mean, s = split_cross(h)
     logs = s if cfg.sr else logscale_of(s)
     z = gaussian_sample(mean, logs, eps_std, eps)
-    for k in reversed(range(cfg.after[level])):
+    for k in reversed(range(_plan_from_state(p, cfg)[1][level])):
         z = flowstep_inverse(z, cf, p, "%s.additional_flow_steps.%d" % (pre, k),
                              cfg.c_perm, cfg.c_coupling, cfg.c_nn_module)
     return z, cf
 
 
 # ------------------------------------------------------------------ FlowNet traversal
+def _plan_from_state(p: P, cfg: NetConfig) -> Tuple[List[dict], List[int]]:
+    """``flow.layers`` re-derived from the STATE DICT alone -- independently of the product's ``config.layer_plan`` -- the way the
+    reference's constructors register their modules (FlowNet_SR_x4.py:33-64, FlowNet_SR_x8.py:33-70, FlowNet_Rescaling_x4.py:33-67):
+    a level opens with a squeeze (parameter-free, or Haar with its frozen filters), the flow steps are the indices that own an
+    ActNorm, a parameter-free Split closes the level; channel counts come from the tensors' shapes (ActNorm bias = C, the prior
+    head's ``f.logs`` = 2 (C - n_split)); AffineCoupling3shift's mode from its DenseBlock's input width (3 = LR vs others,
+    AffineCouplings.py:118-160). Returns (plan, additional flow steps per level)."""
+    steps = {}
+    for k, v in p.items():
+        m = re.match(r"flow\.layers\.(\d+)\.actnorm\.bias$", k)
+        if m:
+            steps[int(m.group(1))] = int(v.shape[1])
+    L = len({m.group(1) for m in (re.match(r"flow\.level(\d+)_condFlow\.", k) for k in p) if m})
+    after = []
+    for level in range(L):
+        pre = "flow.level%d_condFlow.additional_flow_steps." % level
+        after.append(len({k[len(pre):].split(".")[0] for k in p if k.startswith(pre)}))
+    plan, idx, C = [], 0, 3
+    for level in range(L):
+        plan.append({"idx": idx, "type": "squeeze", "level": level, "C_in": C})
+        idx += 1
+        C *= 4
+        while idx in steps:
+            assert steps[idx] == C, ("flow step %d: ActNorm over %d channels at a %d-channel position" % (idx, steps[idx], C))
+            w = p.get("flow.layers.%d.affine.f.conv1.weight" % idx)
+            lrv = True if (cfg.sr or w is None) else (int(w.shape[1]) == 3)
+            plan.append({"idx": idx, "type": "flowstep", "level": level, "C": C, "lr_vs_others": lrv})
+            idx += 1
+        ns = C - int(p["flow.level%d_condFlow.f.logs" % level].shape[0]) // 2
+        plan.append({"idx": idx, "type": "split", "level": level, "C": C, "n_split": ns})
+        idx += 1
+        C = ns
+    assert not any(i >= idx for i in steps), "flow steps beyond the last split"
+    return plan, after
+
+
 def _up(x, f):
     """F.interpolate(scale_factor=f, mode='nearest') (FlowNet_SR_x4.py:98,117)."""
     return F.interpolate(x, scale_factor=f, mode="nearest")
@@ -415,7 +453,9 @@ def flownet_forward(x, logdet, p: P, cfg: NetConfig):
     z = x
     ys: List[torch.Tensor] = []
     a_s: List[torch.Tensor] = []
-    for ent in layer_plan(cfg):
+    plan, _ = _plan_from_state(p, cfg)
+    L = sum(1 for e in plan if e["type"] == "split")
+    for ent in plan:
         pre = "flow.layers.%d" % ent["idx"]
         if ent["type"] == "squeeze":
             z = haar_forward(z) if cfg.squeeze == "haar" else squeeze2d(z)
@@ -430,9 +470,9 @@ def flownet_forward(x, logdet, p: P, cfg: NetConfig):
     # hierarchical conditional prior, deepest level first (FlowNet_SR_x4.py:95-99, x8:104-114)
     cfs: Dict[int, torch.Tensor] = {}
     fake_z: Dict[int, torch.Tensor] = {}
-    for level in reversed(range(cfg.L)):
+    for level in reversed(range(L)):
         u = [ys[level]]
-        for l2 in range(level + 1, cfg.L):
+        for l2 in range(level + 1, L):
             u.append(_up(cfs[l2], 2 ** (l2 - level)))
         u = torch.cat(u, 1) if len(u) > 1 else u[0]
         r, cf = condflow_forward(a_s[level], u, logdet, p, "flow.level%d_condFlow" % level, cfg, level)
@@ -441,7 +481,7 @@ def flownet_forward(x, logdet, p: P, cfg: NetConfig):
             logdet = r
         else:
             fake_z[level] = r
-    return z, logdet, [fake_z[l] for l in range(cfg.L)] if not cfg.sr else None
+    return z, logdet, [fake_z[l] for l in range(L)] if not cfg.sr else None
 
 
 def flownet_inverse(z, p: P, cfg: NetConfig, eps_std, eps: Optional[Sequence[torch.Tensor]] = None):
@@ -449,7 +489,9 @@ def flownet_inverse(z, p: P, cfg: NetConfig, eps_std, eps: Optional[Sequence[tor
     FlowNet_Rescaling_x4.py:111-128)."""
     cfs: Dict[int, torch.Tensor] = {}
     draw = 0
-    for ent in reversed(layer_plan(cfg)):
+    plan, _ = _plan_from_state(p, cfg)
+    L = sum(1 for e in plan if e["type"] == "split")
+    for ent in reversed(plan):
         pre = "flow.layers.%d" % ent["idx"]
         if ent["type"] == "flowstep":
             z = flowstep_inverse(z, None, p, pre, cfg.perm, cfg.coupling, cfg.nn_module,
@@ -459,7 +501,7 @@ def flownet_inverse(z, p: P, cfg: NetConfig, eps_std, eps: Optional[Sequence[tor
         else:
             level = ent["level"]
             u = [z]
-            for l2 in range(level + 1, cfg.L):
+            for l2 in range(level + 1, L):
                 u.append(_up(cfs[l2], 2 ** (l2 - level)))
             u = torch.cat(u, 1) if len(u) > 1 else u[0]
             e = None if eps is None else eps[draw]

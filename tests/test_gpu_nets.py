@@ -10,8 +10,8 @@ from tests.util import load_golden, params_for, t, maxdiff, cached_params
 
 pytestmark = pytest.mark.gpu
 
-# net_var_*: reference-generated fixtures for depth / split / trunk variants (the option space of tests/test_gpu_fuzz.py, whose
-# oracle shares layer_plan with the product: these do not)
+# net_var_*: reference-generated fixtures for depth / split / trunk variants (the option space of tests/test_gpu_fuzz.py; since
+# round 5 the oracle derives the layer structure from the state dict itself, not from the product's config.layer_plan)
 NETS_SR = ["net_sr4_tiny", "net_sr8_tiny", "net_sr4_full", "net_sr8_full", "net_var_sr4_a", "net_var_sr4_b", "net_var_sr8_a",
            "net_var_sr8_b"]
 NETS_RS = ["net_rescale_tiny", "net_rescale_full", "net_var_rescale_a", "net_var_rescale_b"]
