@@ -388,6 +388,17 @@ class _RescaleForwardStep(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+_POOL = []
+
+
+def _enqueue_pool():
+    """One helper thread per process that enqueues the second half batch of a split inference call (see _run_checked)."""
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="hcflow-enqueue"))
+    return _POOL[0]
+
+
 # ------------------------------------------------------------------ engine-backed top modules
 class _EngineModule(nn.Module):
     """Shared plumbing: parameter upload / repack tracking and raw-pointer calls into the C ABI."""
@@ -418,7 +429,8 @@ class _EngineModule(nn.Module):
         # OPT-IN (HCFLOW_STREAMS=2 or set_streams(2)): inference calls of >= 4 samples run as TWO half batches on two HIP streams of
         # the GPU (two engines): every op of the path is per-sample, the convolutions are persistent one-block-per-CU launches,
         # and the second stream's kernels fill the ragged last rounds and launch boundaries of the first's. Measured same-box
-        # (profiles/r05_notes.md section 4): config 2 +2.8 %, config 4 +6..12 %, Face x8 +-0; NOT the default because (i) the
+        # (profiles/r05_notes.md section 4): config 2 +2.8 % (+4.5 % with the second half enqueued by a helper thread), config 4
+        # +6..12 %, Face x8 +-0; NOT the default because (i) the
         # kernels of the two streams overlap, so per-kernel durations (HIP events, rocprofv3) no longer add up to the step and the
         # roofline bookkeeping of bench.py loses its meaning, and (ii) a process that also trains runs out of hardware queues
         # (HIP maps streams onto 4 of them: the training pass' weight-gradient stream then shares one with its dependency chain).
@@ -581,7 +593,7 @@ class _EngineModule(nn.Module):
     def _params(self):
         return [p for _, p in self._tensors()]
 
-    def _run_checked(self, eng, idx, call, what, batch=0, call_sample=None, parts=None):
+    def _run_checked(self, eng, idx, call, what, batch=0, call_sample=None, parts=None, threaded=False):
         """One inference pass through the C ABI under the range-check policy. ``call(eng, lo, hi, stream)`` enqueues samples
         [lo, hi) on ``eng`` and returns the status. ``parts`` (optional): [(engine, lo, hi, torch stream or None)] -- the split of a
         batch over the device's engines / streams (None = the caller's stream); the side streams are joined before returning.
@@ -592,15 +604,27 @@ class _EngineModule(nn.Module):
             cur = torch.cuda.current_stream(idx)
             if parts is None:
                 parts = [(eng, 0, batch, None)]
-            for e_, lo, hi, st_ in parts:
-                if st_ is None:
-                    _lib.check(call(e_, lo, hi, C.c_void_p(cur.cuda_stream)), e_.handle, what)
-                else:
+            if len(parts) == 1:
+                e_, lo, hi, _ = parts[0]
+                _lib.check(call(e_, lo, hi, C.c_void_p(cur.cuda_stream)), e_.handle, what)
+            else:
+                # two half batches on two side streams. ``threaded`` (large samples): the second half's launches are enqueued by a
+                # helper thread WHILE this thread enqueues the first half's (ctypes drops the GIL inside the C call): config 2
+                # +4.5 % instead of +2.8 % (profiles/r05_notes.md section 4). At small grids (Face x8) the hand-over and the two
+                # threads' contention inside the HIP runtime cost more than they bring (-25 %): there the halves are enqueued in turn
+                for _, _, _, st_ in parts:
                     st_.wait_stream(cur)                          # the inputs were produced on the caller's stream
-                    with torch.cuda.stream(st_):
-                        _lib.check(call(e_, lo, hi, C.c_void_p(st_.cuda_stream)), e_.handle, what)
-            for _, _, _, st_ in parts:
-                if st_ is not None:
+                (e0, lo0, hi0, s0), (e1, lo1, hi1, s1) = parts
+                if threaded:
+                    fut = _enqueue_pool().submit(call, e1, lo1, hi1, C.c_void_p(s1.cuda_stream))
+                    rc0 = call(e0, lo0, hi0, C.c_void_p(s0.cuda_stream))
+                    rc1 = fut.result()
+                else:
+                    rc0 = call(e0, lo0, hi0, C.c_void_p(s0.cuda_stream))
+                    rc1 = call(e1, lo1, hi1, C.c_void_p(s1.cuda_stream))
+                _lib.check(rc0, e0.handle, what)
+                _lib.check(rc1, e1.handle, what)
+                for _, _, _, st_ in parts:
                     cur.wait_stream(st_)                          # joined: the output is complete on the caller's stream
             if self._precision[0] != "f16x3" or self._range_check[0] != "sync":
                 return
@@ -797,7 +821,7 @@ class _EngineModule(nn.Module):
         def one_sample(b):
             return run(eng, b, b + 1, self._stream(idx), flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND))
         self._run_checked(eng, idx, run, "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample,
-                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond))
+                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond), threaded=h * w >= 4096)
         return out
 
     # convenience for benchmarks / multi-GPU sharding
@@ -918,7 +942,8 @@ class HCFlowNet_Rescaling(_EngineModule):
         fl = (0 if clamp else _lib.FLAG_NO_CLAMP) | (_lib.FLAG_NO_RANGE_CHECK if self._range_check[0] == "off" else 0)
         self._run_checked(eng, idx, lambda e_, lo, hi, stream: e_.lib.hcf_forward_rescale(
             e_.handle, hr[lo:hi].data_ptr(), out_lr[lo:hi].data_ptr(), z1[lo:hi].data_ptr(), z2[lo:hi].data_ptr(), hi - lo, H, W,
-            fl, stream), "hcf_forward_rescale", batch=B, parts=self._parts(dev, idx, eng, B, allow=not pend))
+            fl, stream), "hcf_forward_rescale", batch=B, parts=self._parts(dev, idx, eng, B, allow=not pend),
+            threaded=H * W >= 65536)
         self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 
