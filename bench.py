@@ -81,6 +81,67 @@ GFLOP_RESCALE_ROUNDTRIP = 1087.69     # rescaling x4 forward + inverse, one 640x
 GFLOP_TRAIN_SAMPLE = 184.27 * 3.0     # SR x4 NLL step, one 160x160 HR sample: forward x ~3 with the backward pass
 
 
+class PowerSampler:
+    """Package power and shader clock of this rank's GPU while the timed region runs: a thread reads the amdgpu hwmon files
+    (power1_input in uW, power1_cap, freq1_input = sclk in Hz) every 20 ms. MI355X runs this workload AT its 1400 W package cap
+    (profiles/r05_notes.md section 9): the board's power management sets the clock, so `frac_of_cap` says how much of the gap
+    between `roofline.frac` and 1 is the chip clocking down rather than the kernel idling. None when the files are not there."""
+
+    def __init__(self, local_rank=0):
+        import glob
+        self.dir = None
+        cands = sorted(d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.isfile(os.path.join(d, "power1_input")))
+        if cands:
+            self.dir = cands[min(local_rank, len(cands) - 1)] if len(cands) > 1 else cands[0]
+        self.how = ("the only amdgpu hwmon node with power1_input" if len(cands) == 1 else
+                    "hwmon node #%d of %d in path order (assumed = HIP device order)" % (min(local_rank, max(len(cands) - 1, 0)), len(cands)))
+        self.p, self.f, self._stop, self._t = [], [], None, None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fh:
+                return float(fh.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def __enter__(self):
+        if self.dir is None:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                pw, fq = self._read("power1_input"), self._read("freq1_input")
+                if pw is not None:
+                    self.p.append(pw * 1e-6)
+                if fq is not None:
+                    self.f.append(fq * 1e-6)
+                self._stop.wait(0.02)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._t is not None:
+            self._stop.set()
+            self._t.join()
+        return False
+
+    def block(self):
+        if self.dir is None or len(self.p) < 3:
+            return None
+        p = self.p[1:]                              # (the first sample predates the region's first kernels)
+        cap = self._read("power1_cap")
+        cap = cap * 1e-6 if cap else None
+        f = self.f[1:] if len(self.f) > 1 else self.f
+        return {"avg_W": round(sum(p) / len(p), 1), "max_W": round(max(p), 1), "cap_W": cap,
+                "frac_of_cap": round(sum(p) / len(p) / cap, 3) if cap else None,
+                "sclk_MHz_avg": round(sum(f) / len(f), 0) if f else None, "sclk_MHz_nominal": 2400, "samples": len(p),
+                "source": "amdgpu hwmon power1_input / power1_cap / freq1_input, sampled every 20 ms by a host thread during the timed "
+                          "region (%s); the driver's own averaging window applies" % self.how}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,10 +267,13 @@ def main():
             def one(i):
                 keep["out"] = step(i)
             # barrier + synchronize | exactly `steps` steps | barrier + synchronize, MAX over ranks (hcflow_amd/dist.py)
-            dt = timed_region(one, steps, first=warmup)
+            with PowerSampler(local) as ps:
+                dt = timed_region(one, steps, first=warmup)
             eng.profile_convs(False)
         assert bool(torch.isfinite(keep["out"]).all())
-        return dt, roofline_block(eng, mode, steps, dt)
+        roof = roofline_block(eng, mode, steps, dt)
+        roof["power"] = ps.block()
+        return dt, roof
 
     def roofline_block(eng, mode, steps, dt):
         variants = []
@@ -405,6 +469,8 @@ def train_workload(args, dev, world, rank):
     net = net.to(dev).train().set_precision(args.precision)
     ddp = wrap_ddp(net, dev)                                          # ONE module / engine / wrap for both optimiser variants
 
+    power = {}
+
     def run(native):
         net.load_state_dict(params, strict=True)                      # both variants start from the same weights (in-place copy)
         ps = [q for q in net.parameters() if q.requires_grad]        # the reference builds its optimiser AFTER the wrap (:118)
@@ -418,7 +484,9 @@ def train_workload(args, dev, world, rank):
             keep["nll"] = train_step(ddp, hr, lr, opt, clip, 100.0)
         for i in range(max(2, args.warmup)):                          # >= 2: step 1 builds plans / buckets, step 2 sees a device refresh
             one(i)
-        dt = timed_region(one, args.steps, first=args.warmup)
+        with PowerSampler(int(os.environ.get("LOCAL_RANK", "0"))) as psamp:
+            dt = timed_region(one, args.steps, first=args.warmup)
+        power[native] = psamp.block()
         nll = float(keep["nll"])
         assert nll == nll, "NLL is NaN"
         # phase split of ONE more step with host syncs between the phases (outside the timed region: the syncs break the overlap
@@ -469,7 +537,7 @@ def train_workload(args, dev, world, rank):
             "detail": first,
             "other_optimizer": dict(second, optimizer=names[args.optim != "native"]),
             "roofline": {"bound": "mfma", "achieved": round(first["mfma_frac"] * peak, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": first["mfma_frac"], "traffic": None,
+                         "frac": first["mfma_frac"], "traffic": None, "power": power.get(args.optim == "native"),
                          "note": "whole step: algorithmic FLOPs (forward 184.27 GFLOP per sample x ~3 with the backward pass, BASELINE.md "
                                  "section 2) / step time, per GPU; per-kernel tables of this step: profiles/rNN_kernel_stats_train_step_*"},
             "cpu_baseline": None,

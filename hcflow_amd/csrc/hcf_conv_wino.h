@@ -74,6 +74,7 @@ struct Args {
   const float* f_bias; const float* f_scale; int f_act;
   int* ovf;
   const char* zeros;       // >= 64 bytes of zeros
+  int rev;                 // walk the units in reverse order (the engine alternates per launch: the consumer starts on what the producer touched last, which the 256 MB MALL still holds)
   int top_wait;            // A/B knob (HCF_WINO_TOP_WAIT=1): the 64-channel kernel waits at the top of every unit's first chunk as before round 5
   unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
 };
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
   //  instead of being hoisted into loop-invariant registers that then spill)
 #define W2_SETUP_UNIT(U)                                                                           \
   {                                                                                                \
-    const int v_ = xcd_remap((U), nunits);                                                         \
+    const int v_ = a.rev ? nunits - 1 - xcd_remap((U), nunits) : xcd_remap((U), nunits);           \
     unt = __builtin_amdgcn_readfirstlane(v_ % ntn);                                                \
     const int t_ = v_ / ntn;                                                                       \
     ux0 = __builtin_amdgcn_readfirstlane((t_ % tiles_x) * TW);                                     \
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   int ub = 0, uy0 = 0, ux0 = 0, uc = 0;          // DMA cursor
 #define W4_SETUP_UNIT(U)                                                                           \
   {                                                                                                \
-    const int v_ = xcd_remap((U), nunits);                                                         \
+    const int v_ = a.rev ? nunits - 1 - xcd_remap((U), nunits) : xcd_remap((U), nunits);           \
     ux0 = __builtin_amdgcn_readfirstlane((v_ % tiles_x) * TW);                                     \
     uy0 = __builtin_amdgcn_readfirstlane(((v_ / tiles_x) % tiles_y) * TH4);                        \
     ub = __builtin_amdgcn_readfirstlane(v_ / (tiles_x * tiles_y));                                 \

@@ -5,6 +5,7 @@
 #include "hcf_common.h"
 #include <cstdlib>
 #include "hcf_conv_wino.h"
+#include <atomic>
 
 namespace hcf {
 
@@ -150,6 +151,11 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   w.zeros = reinterpret_cast<const char*>(a.zeros);
   static const int top_wait = getenv("HCF_WINO_TOP_WAIT") ? atoi(getenv("HCF_WINO_TOP_WAIT")) : 0;     // A/B knob, read once
   w.top_wait = top_wait;
+  // Consecutive launches walk their units in opposite directions (HCF_WINO_REV=0: all forward): the next conv of a dense block reads
+  // what this one read and wrote, and the part touched last is still in the MALL when the walk starts there (profiles/r05_notes.md section 9).
+  static const int rev_mode = getenv("HCF_WINO_REV") ? atoi(getenv("HCF_WINO_REV")) : 1;
+  static std::atomic<unsigned> rev_flip{0};
+  w.rev = rev_mode ? (int)(rev_flip.fetch_add(1, std::memory_order_relaxed) & 1u) : 0;
   const int ncu = wino_ncu();
   // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
   int only = argc > 1 ? atoi(argv[1]) : -1;
   const int version = argc > 2 ? atoi(argv[2]) : 2;
   int ncu = 0; CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+  if (getenv("NCU")) ncu = atoi(getenv("NCU"));      // fewer resident blocks: how much of a unit's time is contention for HBM / fabric?
   const Prob probs[] = {
       {"check small 64->32  lrelu", 2, 24, 40, 64, 0, 32, 2, false},
       {"check small 64+128->64 res", 1, 17, 70, 64, 128, 64, 0, true},
@@ -200,7 +201,7 @@ int main(int argc, char** argv) {
       else
       { unsigned long long h[8]; CK(hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost));
         if (h[4]) printf("    per wave: life %.0f kcyc (%.2f GHz)  vmcnt %.1f %%  barrier %.1f %%  setup+issue %.1f %%  loads+transform %.1f %%  epilogue %.1f %%\n",
-                         h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 12 * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]);
+                         h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]);
         if (h[4] && h[7]) printf("    of the epilogue: %.1f %% of the life waiting at its first barrier\n", 100.0 * h[7] / h[2]); }
 #endif
     }
