@@ -89,12 +89,22 @@ class PowerSampler:
 
     def __init__(self, local_rank=0):
         import glob
-        self.dir = None
+        self.dir, self.how = None, "no amdgpu hwmon node with power1_input"
         cands = sorted(d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.isfile(os.path.join(d, "power1_input")))
-        if cands:
-            self.dir = cands[min(local_rank, len(cands) - 1)] if len(cands) > 1 else cands[0]
-        self.how = ("the only amdgpu hwmon node with power1_input" if len(cands) == 1 else
-                    "hwmon node #%d of %d in path order (assumed = HIP device order)" % (min(local_rank, max(len(cands) - 1, 0)), len(cands)))
+        bdf = None
+        try:                                        # the node of THIS rank's GPU: PCI address of the HIP device = the card's sysfs device
+            import torch
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001
+            pass
+        for d in cands:
+            if bdf and os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(d)))) == bdf:
+                self.dir, self.how = d, "hwmon node of PCI device %s = HIP device %d" % (bdf, local_rank)
+        if self.dir is None and len(cands) == 1:
+            self.dir, self.how = cands[0], "the only amdgpu hwmon node with power1_input"
+        elif self.dir is None and cands:
+            self.how = "%d hwmon nodes, none at this device's PCI address %s" % (len(cands), bdf)
         self.p, self.f, self._stop, self._t = [], [], None, None
 
     def _read(self, name):
@@ -130,7 +140,7 @@ class PowerSampler:
 
     def block(self):
         if self.dir is None or len(self.p) < 3:
-            return None
+            return {"avg_W": None, "source": self.how} if self.dir is None else None
         p = self.p[1:]                              # (the first sample predates the region's first kernels)
         cap = self._read("power1_cap")
         cap = cap * 1e-6 if cap else None
@@ -576,8 +586,15 @@ def other_configs(dev, params_sr4, steps, mode):
         return cfg, net.set_precision(mode)
 
     def timed(fn, warmup=3):
-        for i in range(warmup):
+        # at least `warmup` calls AND 1.5 s of continuous GPU work: these configurations follow the CPU baseline's minute of GPU
+        # idleness, and the board's clocks take ~1 s to come back up (r05: config 1 read 26.7 ms instead of 13.7 ms straight after it)
+        tw, i = time.perf_counter(), 0
+        while i < warmup or time.perf_counter() - tw < 1.5:
             fn(i)
+            i += 1
+            if i % 8 == 0:
+                sync()
+        warmup = i
         sync()
         t0 = time.perf_counter()
         for i in range(steps):
