@@ -153,7 +153,8 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   w.top_wait = top_wait;
   // Consecutive launches walk their units in opposite directions (HCF_WINO_REV=0: all forward): the next conv of a dense block reads
   // what this one read and wrote, and the part touched last is still in the MALL when the walk starts there (profiles/r05_notes.md section 9).
-  static const int rev_mode = getenv("HCF_WINO_REV") ? atoi(getenv("HCF_WINO_REV")) : 1;
+  const char* const rev_env = getenv("HCF_WINO_REV");                 // (read per launch: tests switch it inside one process)
+  const int rev_mode = rev_env ? atoi(rev_env) : 1;
   static std::atomic<unsigned> rev_flip{0};
   w.rev = rev_mode ? (int)(rev_flip.fetch_add(1, std::memory_order_relaxed) & 1u) : 0;
   const int ncu = wino_ncu();

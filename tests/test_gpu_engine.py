@@ -279,3 +279,28 @@ def test_trunk_microbatch_knob_is_bit_identical(monkeypatch):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert outs[0] == outs[1], outs
+
+
+def test_reverse_walk_of_winograd_units_is_bit_identical(monkeypatch):
+    """Round 5: consecutive Winograd launches enumerate their units in opposite directions (wino::Args.rev; MALL reuse between a
+    dense block's convs). The order in which units are computed must not change a bit: the same call with every launch walking
+    forward (HCF_WINO_REV=0, read per launch) and with the default alternation -- twice, so both parities of the launch counter
+    meet every conv."""
+    cfg, net = _net("SR_4X_tiny", 11, "f16x3")
+    g = torch.Generator().manual_seed(12)
+    lr = torch.rand(3, 3, 24, 40, generator=g).cuda()       # HR 96 x 160: ragged 8- and 16-row units, several per launch
+    with torch.no_grad():
+        monkeypatch.setenv("HCF_WINO_REV", "0")
+        fwd = net(lr=lr, eps_std=0.8, reverse=True, seed=21)
+        monkeypatch.delenv("HCF_WINO_REV", raising=False)
+        eng = net.engine()
+        eng.profile_convs(True)
+        a = net(lr=lr, eps_std=0.8, reverse=True, seed=21)
+        n_wino = eng.conv_time(9, 0, kind=4, reset=True)[1]
+        eng.profile_convs(False)
+        assert n_wino > 0                                    # the pass does run Winograd launches
+        b = net(lr=lr, eps_std=0.8, reverse=True, seed=21)
+        c = net(lr=lr[:1], eps_std=0.8, reverse=True, seed=21)      # an odd number of launches in between: the parity shifts
+        d = net(lr=lr, eps_std=0.8, reverse=True, seed=21)
+    assert torch.equal(a, fwd) and torch.equal(b, fwd) and torch.equal(d, fwd)
+    assert torch.equal(c, fwd[:1])
