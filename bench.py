@@ -742,6 +742,7 @@ def cpu_baseline(cfg, params, h, passes):
             t2.append(time.perf_counter() - t0)
     med = statistics.median(times)
     c_port = c_port_sample()
+    c_net = c_net_pass(cfg, params, lr, out, phys, ncpu)
     cpu_model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -760,7 +761,7 @@ def cpu_baseline(cfg, params, h, passes):
              "spread_rel": round((max(times) - min(times)) / med, 3), "thread_calibration_s": calib,
              "batch2_throughput": {"value": round(2.0 / min(t2), 4), "unit": "HR images/s", "pass_times_s": [round(t, 3) for t in t2],
                                    "sample": "same net, B=2 LR %dx%d, tau=0, best of 2 passes, %d threads" % (h, h, threads)},
-             "c_port": c_port}, lr, out)
+             "c_port": c_port, "c_net": c_net}, lr, out)
 
 
 def physical_cores():
@@ -781,6 +782,43 @@ def physical_cores():
         return len(seen) or None
     except OSError:
         return None
+
+
+def c_net_pass(cfg, params, lr, ref_out, phys, ncpu):
+    """The WHOLE path in plain C (oracle/hcflow_net.c: scalar loops gcc vectorises, OpenMP over (sample, output-channel block, row
+    band), its own layer plan from the state-dict keys; pinned by the reference-generated fixtures, tests/test_oracle_c_net.py) on
+    every physical core of this host: the same B=1 pass as the PyTorch-CPU figure above, bounded to one timed pass (a quarter-size
+    pass first; the full one only if that projects to under a minute), and compared with the PyTorch oracle's output."""
+    import subprocess
+    import numpy as np
+    try:
+        so = os.path.join(ROOT, "oracle", "_build", "libhcflow_net.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        from oracle import hcflow_c
+        net = hcflow_c.CNet(params, cfg)
+    except Exception as e:                      # noqa: BLE001 -- a side line must never cost the headline
+        return {"skipped": "oracle/_build/libhcflow_net.so unavailable (%s)" % type(e).__name__}
+    threads = net.threads(min(phys, ncpu))
+    h = lr.shape[2]
+    q = max(8, h // 2)
+    t0 = time.perf_counter()
+    net.inverse(lr[:, :, :q, :q].contiguous())
+    tq = time.perf_counter() - t0
+    rec = {"kind": "port", "what": "oracle/hcflow_net.c: the whole inverse pass in plain C + OpenMP", "cores": threads,
+           "threads": threads, "quarter_pass_s": round(tq, 3)}
+    if tq * (h * h) / float(q * q) > 60.0:
+        rec.update({"value": round((q * q) / float(h * h) / tq, 5), "unit": "HR images/s (projected from the %dx%d pass)" % (q, q),
+                    "sample": "B=1 LR %dx%d of the %dx%d patch (the full pass would exceed the bench's CPU budget)" % (q, q, h, h)})
+        return rec
+    t0 = time.perf_counter()
+    out = net.inverse(lr)
+    tf = time.perf_counter() - t0
+    rec.update({"value": round(1.0 / tf, 5), "unit": "HR images/s", "config1_latency_s": round(tf, 3),
+                "sample": "BASELINE config 1, B=1 LR %dx%d, tau=0, one timed pass after a %dx%d warm-up pass" % (h, h, q, q),
+                "gflops": round(GFLOP_PER_IMAGE * (h * h) / (160.0 * 160.0) / tf, 1),
+                "max_abs_diff_vs_pytorch_oracle": float(np.abs(out - ref_out.numpy()).max())})
+    return rec
 
 
 def c_port_sample():
