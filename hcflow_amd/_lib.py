@@ -22,7 +22,7 @@ FLAG_REUSE_COND = 8
 # every symbol include/hcflow.h declares (tests/test_cabi_cpu.py checks the .so exports them all)
 SYMBOLS = [
     "hcf_create", "hcf_destroy", "hcf_last_error", "hcf_param_count", "hcf_param_info",
-    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_inverse_ex", "hcf_check_range", "hcf_check_range_samples", "hcf_forward_sr", "hcf_forward_rescale",
+    "hcf_set_param", "hcf_finalize", "hcf_inverse", "hcf_inverse_ex", "hcf_check_range", "hcf_check_range_samples", "hcf_aux_stream", "hcf_forward_sr", "hcf_forward_rescale",
     "hcf_workspace_bytes", "hcf_weight_bytes", "hcf_profile_convs", "hcf_conv_time_ms",
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.hcf_inverse_ex.argtypes = [vp, fp, C.POINTER(fp), i32, f32, u64, i64, fp, i32, i32, i32, u32, vp]
     lib.hcf_check_range.argtypes = [vp, C.POINTER(i32)]
     lib.hcf_check_range_samples.argtypes = [vp, C.POINTER(i32), C.POINTER(u32)]
+    lib.hcf_aux_stream.argtypes = [i32, i32, C.POINTER(vp)]
     lib.hcf_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.hcf_forward_rescale.argtypes = [vp, fp, fp, fp, fp, i32, i32, i32, u32, vp]
     lib.hcf_workspace_bytes.argtypes = [vp]

@@ -445,9 +445,18 @@ class _EngineModule(nn.Module):
         return self
 
     def _side_stream(self, idx):
+        """Side stream ``idx = (device, slot)``: the PROCESS' pool of two per device (include/hcflow.h: hcf_aux_stream), shared with the
+        engines' training passes, so that a process never holds more than the caller's stream + two (HIP spreads streams over four
+        hardware queues; with streams of its own for the split calls a process that also trained ran its backward pass at 66
+        instead of 37 ms)."""
         st = self._side_streams.get(idx)
         if st is None:
-            st = torch.cuda.Stream(device=idx[0] if isinstance(idx, tuple) else idx)
+            dev, slot = idx
+            h = C.c_void_p()
+            rc = _lib.load().hcf_aux_stream(int(dev), int(slot), C.byref(h))
+            if rc != 0 or not h.value:
+                raise _lib.HcfError("hcf_aux_stream(%d, %d) failed (%d)" % (dev, slot, rc))
+            st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", dev))
             self._side_streams[idx] = st
         return st
 

@@ -24,6 +24,25 @@
 namespace hcf {
 int step_cmax(int C);
 
+// The process' side streams: at most TWO per device, low priority, non-blocking, created on first use and never destroyed. Every
+// engine of the process takes its extra streams from here (training: slot 0 = weight gradients, slot 1 = the conditional features'
+// data gradients; inference: the two half batches of a split call, through hcf_aux_stream), so a process holds the caller's stream
+// + two -- HIP spreads streams over four hardware queues, and a process that trained beside streams of its own for the split
+// inference calls had five (backward pass 37 -> 66 ms: profiles/r05_notes.md section 4).
+hipStream_t aux_stream(int slot) {
+  static hipStream_t pool[64][2] = {};
+  int dev = 0;
+  if (slot < 0 || slot > 1 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pool[dev][slot]) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+    pool[dev][slot] = st;
+  }
+  return pool[dev][slot];
+}
+
 static inline int ru4(int c) { return (c + 3) & ~3; }
 
 // ------------------------------------------------------------------------------------------------
@@ -1562,10 +1581,10 @@ void hcf_destroy(hcf_engine* e) {
   for (auto& t : e->slots) { if (t.a.base) hipFree(t.a.base); if (t.g.base) hipFree(t.g.base); }
   if (e->wg_scratch) hipFree(e->wg_scratch);
   if (e->wg_jobs_dev) hipFree(e->wg_jobs_dev);
-  if (e->wg_stream) { hipStreamSynchronize(e->wg_stream); hipStreamDestroy(e->wg_stream); }
+  if (e->wg_stream) hipStreamSynchronize(e->wg_stream);      // (the stream belongs to the process' pool: aux_stream)
   if (e->wg_ev) hipEventDestroy(e->wg_ev);
   if (e->wg_done) hipEventDestroy(e->wg_done);
-  if (e->dg_stream) { hipStreamSynchronize(e->dg_stream); hipStreamDestroy(e->dg_stream); }
+  if (e->dg_stream) hipStreamSynchronize(e->dg_stream);
   if (e->dg_ev) hipEventDestroy(e->dg_ev);
   if (e->dg_done) hipEventDestroy(e->dg_done);
   if (e->axpy_jobs_dev) hipFree(e->axpy_jobs_dev);
@@ -1577,6 +1596,18 @@ void hcf_destroy(hcf_engine* e) {
 }
 
 const char* hcf_last_error(const hcf_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int hcf_aux_stream(int32_t device, int32_t slot, hcf_stream_t* out) {
+  if (!out || slot < 0 || slot > 1) return HCF_ERR_ARG;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return HCF_ERR_HIP;
+  if (device >= 0 && device != cur && hipSetDevice(device) != hipSuccess) return HCF_ERR_HIP;
+  hipStream_t st = hcf::aux_stream(slot);
+  if (device >= 0 && device != cur) hipSetDevice(cur);
+  if (!st) return HCF_ERR_HIP;
+  *out = (hcf_stream_t)st;
+  return HCF_OK;
+}
 
 int hcf_param_count(const hcf_engine* e) { return e ? (int)e->specs.size() : HCF_ERR_ARG; }
 

@@ -159,6 +159,13 @@ int hcf_check_range(hcf_engine* e, int32_t* overflowed);
 int hcf_check_range_samples(hcf_engine* e, int32_t* overflowed, uint32_t* sample_slots);
 int64_t hcf_fallback_count(const hcf_engine* e);
 
+/* Side stream `slot` (0 / 1) of `device` (-1: the current one): the process holds at most two per device (low priority,
+ * non-blocking, created on first use, never destroyed) and every engine uses them -- the training pass for its weight-gradient and
+ * conditional-feature-gradient work, the module for the two half batches of a split inference call (hcflow_amd/arch.py:
+ * set_streams(2)). Replaces nothing in the reference (it runs on one stream; codes/models/HCFlow_SR_model.py:184-205, 209-262);
+ * exported so that the host side does not create further streams of its own: HIP spreads streams over four hardware queues. */
+int hcf_aux_stream(int32_t device, int32_t slot, hcf_stream_t* out);
+
 /* bytes of device workspace currently held (activations arena) and of packed weights */
 size_t hcf_workspace_bytes(const hcf_engine* e);
 size_t hcf_weight_bytes(const hcf_engine* e);
