@@ -613,6 +613,19 @@ def other_configs(dev, params_sr4, steps, mode):
             "value": round(1e3 * dt, 3), "unit": "ms per call (B=1, LR 160x160 -> 640x640, tau 0)", "higher_is_better": False,
             "ms_per_step": round(1e3 * dt, 3), "images_per_s": round(1.0 / dt, 2),
             "mfma_frac": round(GFLOP_PER_IMAGE / 1e3 / dt / peak, 4)}
+        if os.environ.get("HCF_BENCH_B1_DIAG"):       # diagnosis of the 13.6 / 22 ms bimodality: kernel time against wall time, clock, power
+            e1 = net.engines()[0]
+            e1.profile_convs(True)
+            with PowerSampler(0) as ps1:
+                t0 = time.perf_counter()
+                for i in range(20):
+                    net(lr=lr, z=None, u=None, eps_std=0.0, reverse=True)
+                sync()
+                dtd = (time.perf_counter() - t0) / 20
+            e1.profile_convs(False)
+            kms, kn, _, _ = e1.conv_time(0, 0, reset=True)
+            out["config1_single_patch_latency"]["diag"] = {"ms_per_call_with_events": round(1e3 * dtd, 3), "conv_kernel_ms_per_call": round(kms / 20, 3),
+                                                           "launches": kn // 20, "power": ps1.block(), "workspace_MB": round(e1.workspace_bytes() / 2 ** 20, 1)}
         del net
         # ---- config 3
         cfg, net = build("SR_CelebA_8X")

@@ -497,11 +497,15 @@ class _EngineModule(nn.Module):
         ones autograd must see so that gradients flow back to the wrapped module (HCFlow_SR_model.py:33-36).
         The (owner module, attribute) pairs are resolved once per module OBJECT (walking 1 500-1 900 dotted paths costs
         ~10 ms of Python per call, several times per forward); a replica is a different object and resolves its own."""
-        slots = self._slots_for_self()
+        return list(zip(self._spec_keys, self._tensor_list()))
+
+    def _tensor_list(self):
+        """The tensors of ``_tensors()`` without their keys (the per-call stamp check walks only this: 1 500-1 900 dictionary
+        look-ups; under the default `sync` range policy the Python in front of a call's first launch is GPU idle time)."""
         out = []
-        for key, (obj, name) in zip(self._spec_keys, slots):
+        for obj, name in self._slots_for_self():
             t = obj._parameters.get(name)
-            out.append((key, t if t is not None else getattr(obj, name)))
+            out.append(t if t is not None else getattr(obj, name))
         return out
 
     def _slots_for_self(self):
@@ -557,9 +561,10 @@ class _EngineModule(nn.Module):
             ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
             ent["engine"].set_precision(self._precision[0])
             self._engines[key] = ent
-        named = self._tensors()
-        stamp = tuple((p.data_ptr(), p._version) for _, p in named)
+        tens = self._tensor_list()
+        stamp = tuple([(p.data_ptr(), p._version) for p in tens])
         if ent["stamp"] != stamp:
+            named = list(zip(self._spec_keys, tens))
             eng = ent["engine"]
             self._cond_key.pop(idx, None)
             ptrs = tuple(p.data_ptr() for _, p in named)
