@@ -81,6 +81,23 @@ GFLOP_RESCALE_ROUNDTRIP = 1087.69     # rescaling x4 forward + inverse, one 640x
 GFLOP_TRAIN_SAMPLE = 184.27 * 3.0     # SR x4 NLL step, one 160x160 HR sample: forward x ~3 with the backward pass
 
 
+@contextlib.contextmanager
+def quiet_gc():
+    """Timed regions run with Python's cyclic collector off (as `timeit` does) after one full collection: a generation-2 pass over
+    this process' ~200-300 k tracked objects (three nets of 1 500 tensors each) is a 50-70 ms host pause -- 8 calls of config 1 read
+    22 ms instead of 13.7 ms per call when one fell into them (profiles/r05_notes.md section 10). A caller's own loop pays such a
+    pause every few hundred calls; the module itself no longer allocates per-parameter containers per call."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class PowerSampler:
     """Package power and shader clock of this rank's GPU while the timed region runs: a thread reads the amdgpu hwmon files
     (power1_input in uW, power1_cap, freq1_input = sclk in Hz) every 20 ms. MI355X runs this workload AT its 1400 W package cap
@@ -173,6 +190,7 @@ def main():
                          "exact = fp32 MFMA. The other mode is timed over the same number of steps and reported beside it")
     ap.add_argument("--range-check", default="default", choices=["default", "sync", "lazy", "off"],
                     help="f16x3 range-check policy (default: the module's own default, i.e. what an unmodified test_HCFlow.py gets)")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the timed run of the opt-in two-stream split")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the timed run of the other precision")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the f16x3-vs-exact deviation check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -277,7 +295,7 @@ def main():
             def one(i):
                 keep["out"] = step(i)
             # barrier + synchronize | exactly `steps` steps | barrier + synchronize, MAX over ranks (hcflow_amd/dist.py)
-            with PowerSampler(local) as ps:
+            with PowerSampler(local) as ps, quiet_gc():
                 dt = timed_region(one, steps, first=warmup)
             eng.profile_convs(False)
         assert bool(torch.isfinite(keep["out"]).all())
@@ -367,6 +385,20 @@ def main():
     default_mode = args.precision                       # = the module's default unless overridden on the command line
     other_mode = "exact" if default_mode == "f16x3" else "f16x3"
     dt, roof = timed(default_mode, args.warmup, args.steps)
+    # the module's OPT-IN two-stream split of a call (set_streams(2) / HCFLOW_STREAMS=2: two half batches on the process' two side
+    # streams, +3-4 % on this workload): the same timed region once more, beside the headline. Not the default because overlapping
+    # kernels void the per-kernel durations the roofline block is built from (profiles/r05_notes.md sections 4, 10).
+    two = None
+    if world == 1 and net._nstreams[0] == 1 and B >= 4 and not args.no_two_streams:
+        try:
+            net.set_streams(2)
+            dt2, _ = timed(default_mode, 2, args.steps)
+            two = {"value": round(world * B * args.steps / dt2, 4), "unit": "HR images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
+                   "steps": args.steps, "how": "net.set_streams(2): opt-in, same workload / steps / timing contract"}
+        except Exception as e:  # noqa: BLE001 -- a side line must never cost the headline
+            two = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        finally:
+            net.set_streams(1)
     other = None
     if not args.no_other_precision:
         dt_o, roof_o = timed(other_mode, 1, args.steps)
@@ -436,7 +468,7 @@ def main():
                           "note": "value / roofline are the module's default mode; `other_precision` is the same workload, same "
                                   "number of timed steps, on the other conv kernels",
                           "check": check},
-            "roofline": roof, "other_precision": other, "cpu_baseline": cpu,
+            "roofline": roof, "two_streams": two, "other_precision": other, "cpu_baseline": cpu,
         }
         if world == 1 and not args.no_other_configs and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
             del net, lr, out_all, hr_in
@@ -494,7 +526,7 @@ def train_workload(args, dev, world, rank):
             keep["nll"] = train_step(ddp, hr, lr, opt, clip, 100.0)
         for i in range(max(2, args.warmup)):                          # >= 2: step 1 builds plans / buckets, step 2 sees a device refresh
             one(i)
-        with PowerSampler(int(os.environ.get("LOCAL_RANK", "0"))) as psamp:
+        with PowerSampler(int(os.environ.get("LOCAL_RANK", "0"))) as psamp, quiet_gc():
             dt = timed_region(one, args.steps, first=args.warmup)
         power[native] = psamp.block()
         nll = float(keep["nll"])
@@ -596,11 +628,12 @@ def other_configs(dev, params_sr4, steps, mode):
                 sync()
         warmup = i
         sync()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            fn(warmup + i)
-        sync()
-        return (time.perf_counter() - t0) / steps
+        with quiet_gc():
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fn(warmup + i)
+            sync()
+            return (time.perf_counter() - t0) / steps
 
     out = {}
     g = torch.Generator().manual_seed(77)
@@ -812,23 +845,34 @@ def c_net_pass(cfg, params, lr, ref_out, phys, ncpu):
         net = hcflow_c.CNet(params, cfg)
     except Exception as e:                      # noqa: BLE001 -- a side line must never cost the headline
         return {"skipped": "oracle/_build/libhcflow_net.so unavailable (%s)" % type(e).__name__}
-    threads = net.threads(min(phys, ncpu))
     h = lr.shape[2]
-    q = max(8, h // 2)
-    t0 = time.perf_counter()
-    net.inverse(lr[:, :, :q, :q].contiguous())
-    tq = time.perf_counter() - t0
+    # thread count: the conv loops expose (sample x output-channel blocks x row bands) = 40-160 tasks per layer at these sizes, so
+    # every physical core of a 128-core host is not the fastest setting; calibrated on a quarter-size patch like the PyTorch figure
+    cal = max(8, h // 4)
+    small = lr[:, :, :cal, :cal].contiguous()
+    calib, threads, best = {}, 1, None
+    for c in sorted({c for c in (16, 32, 64, phys) if 1 <= c <= min(phys, ncpu)} or {1}):
+        net.threads(c)
+        t0 = time.perf_counter()
+        net.inverse(small)
+        t = time.perf_counter() - t0
+        calib[str(c)] = round(t, 3)
+        if best is None or t < best:
+            best, threads = t, c
+    net.threads(threads)
     rec = {"kind": "port", "what": "oracle/hcflow_net.c: the whole inverse pass in plain C + OpenMP", "cores": threads,
-           "threads": threads, "quarter_pass_s": round(tq, 3)}
-    if tq * (h * h) / float(q * q) > 60.0:
-        rec.update({"value": round((q * q) / float(h * h) / tq, 5), "unit": "HR images/s (projected from the %dx%d pass)" % (q, q),
-                    "sample": "B=1 LR %dx%d of the %dx%d patch (the full pass would exceed the bench's CPU budget)" % (q, q, h, h)})
+           "threads": threads, "physical_cores": phys, "thread_calibration_s": calib,
+           "calibration_patch": "%dx%d" % (cal, cal)}
+    if best * (h * h) / float(cal * cal) > 60.0:
+        rec.update({"value": round((cal * cal) / float(h * h) / best, 5),
+                    "unit": "HR images/s (projected from the %dx%d pass)" % (cal, cal),
+                    "sample": "B=1 LR %dx%d of the %dx%d patch (the full pass would exceed the bench's CPU budget)" % (cal, cal, h, h)})
         return rec
     t0 = time.perf_counter()
     out = net.inverse(lr)
     tf = time.perf_counter() - t0
     rec.update({"value": round(1.0 / tf, 5), "unit": "HR images/s", "config1_latency_s": round(tf, 3),
-                "sample": "BASELINE config 1, B=1 LR %dx%d, tau=0, one timed pass after a %dx%d warm-up pass" % (h, h, q, q),
+                "sample": "BASELINE config 1, B=1 LR %dx%d, tau=0, one timed pass after the calibration passes" % (h, h),
                 "gflops": round(GFLOP_PER_IMAGE * (h * h) / (160.0 * 160.0) / tf, 1),
                 "max_abs_diff_vs_pytorch_oracle": float(np.abs(out - ref_out.numpy()).max())})
     return rec

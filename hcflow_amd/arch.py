@@ -508,6 +508,13 @@ class _EngineModule(nn.Module):
             out.append(t if t is not None else getattr(obj, name))
         return out
 
+    @staticmethod
+    def _stamp_of(tens):
+        """(addresses, versions) of the parameter tensors as TWO flat lists of ints: 1 500-1 900 (ptr, version) tuples per call were
+        1 500-1 900 GC-tracked containers per call, i.e. a generation-0 collection every other call and, every few dozen calls, a
+        full collection over the process' ~200 k objects -- a 50-70 ms pause in front of a 13 ms call (profiles/r05_notes.md 10)."""
+        return ([p.data_ptr() for p in tens], [p._version for p in tens])
+
     def _slots_for_self(self):
         cached = self.__dict__.get("_slots")
         if cached is not None and cached[0] == id(self):
@@ -562,7 +569,7 @@ class _EngineModule(nn.Module):
             ent["engine"].set_precision(self._precision[0])
             self._engines[key] = ent
         tens = self._tensor_list()
-        stamp = tuple([(p.data_ptr(), p._version) for p in tens])
+        stamp = self._stamp_of(tens)
         if ent["stamp"] != stamp:
             named = list(zip(self._spec_keys, tens))
             eng = ent["engine"]
@@ -728,7 +735,7 @@ class _EngineModule(nn.Module):
         self._broadcast_actnorms(pend)
         # the engine already holds these values: no repack on the next call (unless the broadcast changed them)
         if not self._dist_on():
-            self._engines[idx]["stamp"] = tuple((p.data_ptr(), p._version) for _, p in self._tensors())
+            self._engines[idx]["stamp"] = self._stamp_of(self._tensor_list())
 
     @staticmethod
     def _dist_on():

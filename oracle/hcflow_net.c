@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define PAR_MIN 262144L      /* elements below which an elementwise / copy loop stays on the calling thread */
+
 /* ------------------------------------------------------------------ tensors (dense NCHW fp32) */
 typedef struct { float* d; int B, C, H, W; } T;
 
@@ -26,7 +28,13 @@ static T t_new(int B, int C, int H, int W) {
   return t;
 }
 static void t_free(T* t) { free(t->d); t->d = NULL; }
-static T t_copy(T x) { T o = t_new(x.B, x.C, x.H, x.W); memcpy(o.d, x.d, sizeof(float) * t_n(x)); return o; }
+static T t_copy(T x) {
+  T o = t_new(x.B, x.C, x.H, x.W);
+  const size_t hw = (size_t)x.H * x.W;
+#pragma omp parallel for schedule(static) if ((long)t_n(o) > PAR_MIN)
+  for (int bc = 0; bc < x.B * x.C; ++bc) memcpy(o.d + (size_t)bc * hw, x.d + (size_t)bc * hw, sizeof(float) * hw);
+  return o;
+}
 static T t_wrap(const float* p, int B, int C, int H, int W) {       /* owning copy of caller memory */
   T o = t_new(B, C, H, W); memcpy(o.d, p, sizeof(float) * t_n(o)); return o;
 }
@@ -34,14 +42,17 @@ static T t_wrap(const float* p, int B, int C, int H, int W) {       /* owning co
 static T t_slice(T x, int c0, int c1) {
   T o = t_new(x.B, c1 - c0, x.H, x.W);
   const size_t hw = (size_t)x.H * x.W;
+#pragma omp parallel for collapse(2) schedule(static) if ((long)t_n(o) > PAR_MIN)
   for (int b = 0; b < x.B; ++b)
-    memcpy(o.d + (size_t)b * o.C * hw, x.d + ((size_t)b * x.C + c0) * hw, sizeof(float) * o.C * hw);
+    for (int c = 0; c < o.C; ++c)
+      memcpy(o.d + ((size_t)b * o.C + c) * hw, x.d + ((size_t)b * x.C + c0 + c) * hw, sizeof(float) * hw);
   return o;
 }
 /* x[:, start::2] (thops.split_feature type="cross", thops.py:44-45) */
 static T t_cross(T x, int start) {
   T o = t_new(x.B, (x.C - start + 1) / 2, x.H, x.W);
   const size_t hw = (size_t)x.H * x.W;
+#pragma omp parallel for collapse(2) schedule(static) if ((long)t_n(o) > PAR_MIN)
   for (int b = 0; b < x.B; ++b)
     for (int c = 0; c < o.C; ++c)
       memcpy(o.d + ((size_t)b * o.C + c) * hw, x.d + ((size_t)b * x.C + start + 2 * c) * hw, sizeof(float) * hw);
@@ -53,18 +64,19 @@ static T t_cat(const T* parts, int n) {
   for (int i = 0; i < n; ++i) C += parts[i].C;
   T o = t_new(parts[0].B, C, parts[0].H, parts[0].W);
   const size_t hw = (size_t)o.H * o.W;
-  for (int b = 0; b < o.B; ++b) {
-    int c0 = 0;
-    for (int i = 0; i < n; ++i) {
-      memcpy(o.d + ((size_t)b * C + c0) * hw, parts[i].d + (size_t)b * parts[i].C * hw, sizeof(float) * parts[i].C * hw);
-      c0 += parts[i].C;
+#pragma omp parallel for collapse(2) schedule(static) if ((long)t_n(o) > PAR_MIN)
+  for (int b = 0; b < o.B; ++b)
+    for (int c = 0; c < C; ++c) {
+      int i = 0, c0 = 0;
+      while (c >= c0 + parts[i].C) { c0 += parts[i].C; ++i; }
+      memcpy(o.d + ((size_t)b * C + c) * hw, parts[i].d + ((size_t)b * parts[i].C + (c - c0)) * hw, sizeof(float) * hw);
     }
-  }
   return o;
 }
 /* F.interpolate(scale_factor=f, mode="nearest") (FlowNet_SR_x4.py:98,117) */
 static T t_up(T x, int f) {
   T o = t_new(x.B, x.C, x.H * f, x.W * f);
+#pragma omp parallel for schedule(static) if ((long)t_n(o) > PAR_MIN)
   for (int bc = 0; bc < x.B * x.C; ++bc)
     for (int y = 0; y < o.H; ++y)
       for (int xx = 0; xx < o.W; ++xx)
@@ -126,7 +138,7 @@ static const float* need(Net* n, const char* pre, const char* suf) {
 /* ------------------------------------------------------------------ convolution */
 /* F.conv2d(x, w, bias, stride 1, padding k/2): cross-correlation, as every conv on the path (Basic.py:51,70,350-355,380-384;
  * ConditionalFlow.py:100-103). w is [cout][cin][k][k]. One task = (sample, block of OCB output channels, band of RB rows). */
-#define RB 16
+#define RB 8
 #define OCB 4                                        /* output channels per task: each input row is read once for OCB accumulator rows */
 static T conv2d(T x, const float* w, const float* bias, int Cout, int k) {
   T o = t_new(x.B, Cout, x.H, x.W);
@@ -195,6 +207,7 @@ static T conv_named(Net* n, T x, const char* pre, int with_bias) {
 /* ActNorm2d: (x + bias) * exp(logs) forward, x * exp(-logs) - bias reverse (ActNorms.py:45-66,87-94), in place */
 static void actnorm(T x, const float* bias, const float* logs, int reverse) {
   const size_t hw = (size_t)x.H * x.W;
+#pragma omp parallel for collapse(2) schedule(static) if ((long)t_n(x) > PAR_MIN)
   for (int b = 0; b < x.B; ++b)
     for (int c = 0; c < x.C; ++c) {
       float* p = x.d + ((size_t)b * x.C + c) * hw;
@@ -203,8 +216,16 @@ static void actnorm(T x, const float* bias, const float* logs, int reverse) {
       else for (size_t i = 0; i < hw; ++i) p[i] = (p[i] + bc) * e;
     }
 }
-static void relu_(T x) { const size_t n = t_n(x); for (size_t i = 0; i < n; ++i) x.d[i] = x.d[i] > 0.f ? x.d[i] : 0.f; }
-static void lrelu_(T x) { const size_t n = t_n(x); for (size_t i = 0; i < n; ++i) x.d[i] = x.d[i] >= 0.f ? x.d[i] : 0.2f * x.d[i]; }
+static void relu_(T x) {
+  const long n = (long)t_n(x);
+#pragma omp parallel for schedule(static) if (n > PAR_MIN)
+  for (long i = 0; i < n; ++i) x.d[i] = x.d[i] > 0.f ? x.d[i] : 0.f;
+}
+static void lrelu_(T x) {
+  const long n = (long)t_n(x);
+#pragma omp parallel for schedule(static) if (n > PAR_MIN)
+  for (long i = 0; i < n; ++i) x.d[i] = x.d[i] >= 0.f ? x.d[i] : 0.2f * x.d[i];
+}
 
 /* fp64 Gauss-Jordan inverse with partial pivoting + log|det| (Permutations.py:70 slogdet, :74 inverse(W.double()).float()) */
 static int inverse_f64(const double* Win, int n, double* inv, double* logabsdet) {
@@ -323,6 +344,7 @@ static T conv_zeros(Net* n, T x, const char* pre) {
   const float* logs = need(n, pre, ".logs");
   if (!logs || !y.B) return y;
   const size_t hw = (size_t)y.H * y.W;
+#pragma omp parallel for collapse(2) schedule(static) if ((long)t_n(y) > PAR_MIN)
   for (int b = 0; b < y.B; ++b)
     for (int c = 0; c < y.C; ++c) {
       const float e = expf(logs[c] * 3.f);
@@ -356,7 +378,11 @@ static T dense5(Net* n, T x, const char* pre) {
   for (int j = 1; j <= 4; ++j) t_free(&feats[j]);
   return o;
 }
-static void axpby_(T y, float a, T x) { const size_t n = t_n(y); for (size_t i = 0; i < n; ++i) y.d[i] = y.d[i] * a + x.d[i]; }
+static void axpby_(T y, float a, T x) {
+  const long n = (long)t_n(y);
+#pragma omp parallel for schedule(static) if (n > PAR_MIN)
+  for (long i = 0; i < n; ++i) y.d[i] = y.d[i] * a + x.d[i];
+}
 /* ResidualDenseBlock.forward (Basic.py:379-385): x5 * 0.2 + x */
 static T rdb(Net* n, T x, const char* pre) { T o = dense5(n, x, pre); if (o.B) axpby_(o, 0.2f, x); return o; }
 /* RRDB.forward (Basic.py:394-398) */
@@ -395,6 +421,7 @@ static int coupling(Net* n, T z, const T* u, const char* pre, int three, int den
   if (h.C != (affine ? 2 * nt : nt)) { snprintf(n->err, sizeof n->err, "%s: coupling net returns %d channels for %d", pre, h.C, nt); t_free(&h); return -1; }
   for (int b = 0; b < z.B; ++b) {
     double acc = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : acc) if ((long)nt * (long)hw > PAR_MIN)
     for (int j = 0; j < nt; ++j) {
       float* zp = z.d + ((size_t)b * C + t_lo + j) * hw;
       if (affine) {
@@ -461,6 +488,7 @@ static int flowstep_inverse(Net* n, T* z, const T* u, const char* pre, int invco
 /* squeeze2d / unsqueeze2d factor 2 (Basic.py:127-157): out[b, c*4+i*2+j, h, w] = x[b, c, 2h+i, 2w+j] */
 static T squeeze2d(T x) {
   T o = t_new(x.B, 4 * x.C, x.H / 2, x.W / 2);
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < x.B; ++b) for (int c = 0; c < x.C; ++c) for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j)
     for (int h = 0; h < o.H; ++h) for (int w = 0; w < o.W; ++w)
       o.d[(((size_t)b * o.C + c * 4 + i * 2 + j) * o.H + h) * o.W + w] = x.d[(((size_t)b * x.C + c) * x.H + 2 * h + i) * x.W + 2 * w + j];
@@ -468,6 +496,7 @@ static T squeeze2d(T x) {
 }
 static T unsqueeze2d(T x) {
   T o = t_new(x.B, x.C / 4, 2 * x.H, 2 * x.W);
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < x.B; ++b) for (int c = 0; c < o.C; ++c) for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j)
     for (int h = 0; h < x.H; ++h) for (int w = 0; w < x.W; ++w)
       o.d[(((size_t)b * o.C + c) * o.H + 2 * h + i) * o.W + 2 * w + j] = x.d[(((size_t)b * x.C + c * 4 + i * 2 + j) * x.H + h) * x.W + w];
@@ -478,6 +507,7 @@ static float haar_sign(int k, int i, int j) { return ((k == 1 && j == 1) || (k =
 /* HaarDownsampling forward (Basic.py:470-478): out[b, k*C + c] = sum_ij s_k(i,j) x[b,c,2h+i,2w+j] / 4 */
 static T haar_forward(T x) {
   T o = t_new(x.B, 4 * x.C, x.H / 2, x.W / 2);
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < x.B; ++b) for (int c = 0; c < x.C; ++c) for (int k = 0; k < 4; ++k)
     for (int h = 0; h < o.H; ++h) for (int w = 0; w < o.W; ++w) {
       float acc = 0.f;
@@ -490,6 +520,7 @@ static T haar_forward(T x) {
 static T haar_inverse(T y) {
   const int C = y.C / 4;
   T o = t_new(y.B, C, 2 * y.H, 2 * y.W);
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < y.B; ++b) for (int c = 0; c < C; ++c) for (int h = 0; h < y.H; ++h) for (int w = 0; w < y.W; ++w)
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
       float acc = 0.f;

@@ -11,11 +11,11 @@ export TMPDIR=/tmp
 cd $ROOT
 timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-two-streams > $OUT/kt.log 2>&1
 python $ROOT/tools/rocpd_summary.py $OUT/kt > $OUT/kernel_stats.txt 2>> $OUT/kt.log
 rm -rf $OUT/kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check --no-other-precision --no-other-configs > $OUT/pmc_$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-check --no-other-precision --no-other-configs --no-two-streams > $OUT/pmc_$c.log 2>&1
 done
 python $ROOT/tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/traffic_pmc.json 2> $OUT/traffic.err
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
