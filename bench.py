@@ -22,6 +22,11 @@ fp32-MFMA kernels with its own roofline block, and `precision.check` gives the d
 The module runs with ITS DEFAULT range-check policy ("sync": every call reads the f16x3 range flag before it returns and would
 re-run an overflowed pass exactly; `precision.range_check` names the policy that was timed; --range-check lazy defers the check).
 
+Streams: the module's default runs a call of >= 4 samples as two half batches on two HIP streams (hcflow_amd/arch.py: set_streams);
+`value` / `ms_per_step` are that default's. Kernels of the two streams overlap, so the `roofline` block is taken from a SECOND timed
+region of the same K steps with the split off (`single_stream`: its value / ms_per_step; `roofline.measured_in` says so) -- the
+per-kernel durations rocprofv3 reports under HCFLOW_STREAMS=1 (profiles/). Timed regions run with Python's cyclic GC off (quiet_gc).
+
 The JSON line also carries
   roofline      dominant kernel = the conv kernel TEMPLATE FAMILY (e.g. conv_wino4_kernel<0|1|2>: the same code with 0 / 1 / 2
                 residual inputs in its epilogue, listed by rocprofv3 as three rows) with the LARGEST TOTAL TIME in the timed
@@ -35,7 +40,8 @@ The JSON line also carries
                 GPU's shard, the NLL training step -- value, unit, ms_per_step, mfma_frac each (N = 1 only; --no-other-configs)
   cpu_baseline  the CPU oracle (oracle/hcflow_oracle.py, a PyTorch-CPU port of the reference path) on this host:
                 BASELINE config 1 (B=1, tau=0, same LR size), median of >= 5 timed passes, rank 0, N = 1 only; its output is
-                kept and compared with the engine's on the same LR (precision.check.max_abs_diff_vs_cpu_path).
+                kept and compared with the engine's on the same LR (precision.check.max_abs_diff_vs_cpu_path). `c_net`: the same
+                pass through the plain-C + OpenMP restatement of the whole path (oracle/hcflow_net.c).
 """
 import argparse
 import contextlib
@@ -190,7 +196,9 @@ def main():
                          "exact = fp32 MFMA. The other mode is timed over the same number of steps and reported beside it")
     ap.add_argument("--range-check", default="default", choices=["default", "sync", "lazy", "off"],
                     help="f16x3 range-check policy (default: the module's own default, i.e. what an unmodified test_HCFlow.py gets)")
-    ap.add_argument("--no-two-streams", action="store_true", help="skip the timed run of the opt-in two-stream split")
+    ap.add_argument("--no-single-stream-leg", action="store_true",
+                    help="skip the second timed region with the two-stream split off (the roofline block then comes from the "
+                         "headline region: only meaningful under HCFLOW_STREAMS=1, e.g. inside rocprofv3)")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the timed run of the other precision")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the f16x3-vs-exact deviation check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -385,25 +393,35 @@ def main():
     default_mode = args.precision                       # = the module's default unless overridden on the command line
     other_mode = "exact" if default_mode == "f16x3" else "f16x3"
     dt, roof = timed(default_mode, args.warmup, args.steps)
-    # the module's OPT-IN two-stream split of a call (set_streams(2) / HCFLOW_STREAMS=2: two half batches on the process' two side
-    # streams, +3-4 % on this workload): the same timed region once more, beside the headline. Not the default because overlapping
-    # kernels void the per-kernel durations the roofline block is built from (profiles/r05_notes.md sections 4, 10).
-    two = None
-    if world == 1 and net._nstreams[0] == 1 and B >= 4 and not args.no_two_streams:
+    # The module's default runs a call of >= 4 samples as two half batches on two HIP streams (two engines); their kernels overlap, so
+    # HIP-event durations taken in that region do not add up to the step. The roofline block therefore comes from a SECOND timed
+    # region of the same steps with the split off (net.set_streams(1)): per-kernel launch durations as rocprofv3 sees them under
+    # HCFLOW_STREAMS=1 (profiles/). `value` / `ms_per_step` are the default region's; the single-stream region's are in the block.
+    single = None
+    split_on = net._nstreams[0] >= 2 and B >= 4
+    if split_on and not args.no_single_stream_leg:
+        headline_power = roof.get("power")
+        net.set_streams(1)
         try:
-            net.set_streams(2)
-            dt2, _ = timed(default_mode, 2, args.steps)
-            two = {"value": round(world * B * args.steps / dt2, 4), "unit": "HR images/s", "ms_per_step": round(1e3 * dt2 / args.steps, 3),
-                   "steps": args.steps, "how": "net.set_streams(2): opt-in, same workload / steps / timing contract"}
-        except Exception as e:  # noqa: BLE001 -- a side line must never cost the headline
-            two = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            dt1, roof = timed(default_mode, 2, args.steps)
         finally:
-            net.set_streams(1)
+            net.set_streams(2)
+        single = {"value": round(world * B * args.steps / dt1, 4), "unit": "HR images/s", "ms_per_step": round(1e3 * dt1 / args.steps, 3),
+                  "steps": args.steps, "power": roof.get("power")}
+        roof["power"] = headline_power
+        roof["measured_in"] = ("single-stream timed region (net.set_streams(1), same workload / steps / timing contract: %.2f HR img/s, "
+                               "%.2f ms per step): the default's two half-batch streams overlap their kernels, whose event durations "
+                               "then do not add up to the step; `power` is the headline (two-stream) region's"
+                               % (single["value"], single["ms_per_step"]))
     other = None
     if not args.no_other_precision:
-        dt_o, roof_o = timed(other_mode, 1, args.steps)
+        net.set_streams(1)                                # (one stream: this leg's per-kernel table is what it is reported for)
+        try:
+            dt_o, roof_o = timed(other_mode, 1, args.steps)
+        finally:
+            net.set_streams(2 if split_on else net._nstreams[0])
         other = {"mode": other_mode, "value": round(world * B * args.steps / dt_o, 4), "unit": "HR images/s",
-                 "ms_per_step": round(1e3 * dt_o / args.steps, 3), "steps": args.steps, "roofline": roof_o}
+                 "ms_per_step": round(1e3 * dt_o / args.steps, 3), "steps": args.steps, "streams": 1, "roofline": roof_o}
     # same inputs / same device eps in both precisions: deviation of the default mode from the exact fp32-MFMA kernels
     check = None
     if not args.no_exact_check:
@@ -459,8 +477,8 @@ def main():
                                       "inverse sampling (netG reverse=True)", B, h, h, h * cfg.scale, h * cfg.scale, args.tau),
                        "global_batch": world * B, "lr_size": h, "tau": args.tau, "parallelism": "dp%d" % world,
                        "streams_per_gpu": (2 if net._nstreams[0] >= 2 and B >= 4 else 1),
-                       "streams_note": "module default 1; HCFLOW_STREAMS=2 runs a call of >= 4 samples as two half batches on two HIP "
-                                       "streams (opt-in: +2.8 % here, but overlapping kernels void the per-kernel roofline bookkeeping)",
+                       "streams_note": "module default: a call of >= 4 samples runs as two half batches on the process' two side HIP "
+                                       "streams (HCFLOW_STREAMS=1 / set_streams(1): one stream; `single_stream` is that region)",
                        "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2),
                        "weights_MB": round(eng.weight_bytes() / 2 ** 20, 1)},
             "precision": {"mode": default_mode, "is_module_default": default_mode == "f16x3",
@@ -468,7 +486,7 @@ def main():
                           "note": "value / roofline are the module's default mode; `other_precision` is the same workload, same "
                                   "number of timed steps, on the other conv kernels",
                           "check": check},
-            "roofline": roof, "two_streams": two, "other_precision": other, "cpu_baseline": cpu,
+            "roofline": roof, "single_stream": single, "other_precision": other, "cpu_baseline": cpu,
         }
         if world == 1 and not args.no_other_configs and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
             del net, lr, out_all, hr_in

@@ -399,6 +399,13 @@ def _enqueue_pool():
     return _POOL[0]
 
 
+def _split_threaded(lr_pixels: int) -> bool:
+    """Second half of a split call enqueued by the helper thread? Default: yes (Face x8 at LR 20 x 20: 1 542 against 1 403 img/s with
+    one thread enqueueing both halves, 1 416 unsplit; the -25 % once measured for this case was a garbage-collection pause inside
+    an 8-call timing loop). HCF_SPLIT_THREADED=0 turns it off (A/B knob)."""
+    return os.environ.get("HCF_SPLIT_THREADED", "1") == "1"
+
+
 # ------------------------------------------------------------------ engine-backed top modules
 class _EngineModule(nn.Module):
     """Shared plumbing: parameter upload / repack tracking and raw-pointer calls into the C ABI."""
@@ -426,20 +433,20 @@ class _EngineModule(nn.Module):
         # check_range() (the calls only enqueue: CUDA-graph capturable); "off" skips the read-back altogether.
         object.__setattr__(self, "_range_check", [os.environ.get("HCFLOW_RANGE_CHECK", "sync")])
         object.__setattr__(self, "_cond_key", {})
-        # OPT-IN (HCFLOW_STREAMS=2 or set_streams(2)): inference calls of >= 4 samples run as TWO half batches on two HIP streams of
-        # the GPU (two engines): every op of the path is per-sample, the convolutions are persistent one-block-per-CU launches,
-        # and the second stream's kernels fill the ragged last rounds and launch boundaries of the first's. Measured same-box
-        # (profiles/r05_notes.md section 4): config 2 +2.8 % (+4.5 % with the second half enqueued by a helper thread), config 4
-        # +6..12 %, Face x8 +-0; NOT the default because (i) the
-        # kernels of the two streams overlap, so per-kernel durations (HIP events, rocprofv3) no longer add up to the step and the
-        # roofline bookkeeping of bench.py loses its meaning, and (ii) a process that also trains runs out of hardware queues
-        # (HIP maps streams onto 4 of them: the training pass' weight-gradient stream then shares one with its dependency chain).
-        object.__setattr__(self, "_nstreams", [max(1, min(2, int(os.environ.get("HCFLOW_STREAMS", "1"))))])
+        # DEFAULT since round 5 (HCFLOW_STREAMS=1 or set_streams(1) turns it off): inference calls of >= 4 samples run as TWO half
+        # batches on the process' two side streams (hcf_aux_stream; two engines: own workspace and packs, the same parameter
+        # tensors), the second half enqueued by a helper thread while this one enqueues the first: every op of the path is
+        # per-sample, the convolutions are persistent one-block-per-CU launches, and the second stream's kernels fill the ragged
+        # last rounds and launch boundaries of the first's. Same box, GC-quiet loops (profiles/r05_notes.md sections 4, 10):
+        # config 2 +3-4 %, config 4 +8-9 %, Face x8 +9 %; B = 1 calls and the training pass are unaffected (the side streams are
+        # the two the training pass uses as well). Overlapping kernels void per-kernel durations (HIP events, rocprofv3): bench.py
+        # takes its roofline block from a single-stream leg.
+        object.__setattr__(self, "_nstreams", [max(1, min(2, int(os.environ.get("HCFLOW_STREAMS", "2"))))])
         object.__setattr__(self, "_side_streams", {})
 
     def set_streams(self, n: int):
-        """1 (default): every call runs on the caller's stream with one engine; 2: inference calls of >= 4 samples are split
-        into two half batches that run side by side on two side streams (joined before the call returns)."""
+        """2 (default): inference calls of >= 4 samples are split into two half batches that run side by side on the process' two
+        side streams (joined before the call returns); 1: every call runs on the caller's stream with one engine."""
         assert n in (1, 2), n
         self._nstreams[0] = int(n)
         return self
@@ -842,7 +849,7 @@ class _EngineModule(nn.Module):
         def one_sample(b):
             return run(eng, b, b + 1, self._stream(idx), flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND))
         self._run_checked(eng, idx, run, "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample,
-                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond), threaded=h * w >= 4096)
+                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond), threaded=_split_threaded(h * w))
         return out
 
     # convenience for benchmarks / multi-GPU sharding
