@@ -821,11 +821,15 @@ class _EngineModule(nn.Module):
         flags = 0 if clamp else _lib.FLAG_NO_CLAMP
         if self._range_check[0] == "off":
             flags |= _lib.FLAG_NO_RANGE_CHECK
+        parts = self._parts(dev, idx, eng, B)
         if cache_cond:
             # the caller's tensor identity + version stand for its contents; any parameter change drops the key (_engine_for)
             # The keyed tensor is HELD while its key is live: a freed tensor's address is handed to the next same-shape batch
             # by the caching allocator (with _version 0 again), which would otherwise hit the key with other contents.
-            key = (lr_in.data_ptr(), lr_in._version, tuple(lr_in.shape), str(lr_in.dtype), str(lr_in.device))
+            # The split layout is part of the key: each engine of a split call keeps ITS half's features, so a call that is split
+            # differently from the one that filled the caches (set_streams in between) must refill them.
+            key = (lr_in.data_ptr(), lr_in._version, tuple(lr_in.shape), str(lr_in.dtype), str(lr_in.device),
+                   0 if parts is None else len(parts))
             have = self._cond_key.get(idx)
             hit = have is not None and have[0] == key and have[1] is lr_in
             flags |= _lib.FLAG_REUSE_COND if hit else _lib.FLAG_KEEP_COND
@@ -849,7 +853,7 @@ class _EngineModule(nn.Module):
         def one_sample(b):
             return run(eng, b, b + 1, self._stream(idx), flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND))
         self._run_checked(eng, idx, run, "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample,
-                          parts=self._parts(dev, idx, eng, B, allow=not cache_cond), threaded=_split_threaded(h * w))
+                          parts=parts, threaded=_split_threaded(h * w))
         return out
 
     # convenience for benchmarks / multi-GPU sharding

@@ -107,7 +107,7 @@ def test_range_overflow_is_rerun_exactly_in_sync_mode_and_reported_in_lazy_mode(
 
 @pytest.mark.parametrize("name", ["SR_4X_tiny", "Rescaling_4X_tiny"])
 def test_two_stream_split_equals_the_single_stream_call(name):
-    """set_streams(2) (opt-in): a call of >= 4 samples runs as two half batches on two side streams / two engines, joined before it
+    """set_streams(2) (the default): a call of >= 4 samples runs as two half batches on two side streams / two engines, joined before it
     returns. Every op is per-sample and the device draws are indexed by the global sample, so the outputs equal the one-stream
     call's bit for bit (tiny nets: same kernel schedule at every batch size) -- sampling path, injected eps, the rescaling
     forward, and the per-sample range fallback across the two halves."""
@@ -117,7 +117,9 @@ def test_two_stream_split_equals_the_single_stream_call(name):
     lr = torch.rand(6, 3, 12, 16, generator=g).cuda()
     eps = [torch.randn(s, generator=g).cuda() * 0.6 for s in eps_shapes(cfg, 6, 12, 16)]
     with torch.no_grad():
+        net.set_streams(1)
         one = [net(lr=lr, eps_std=0.6, reverse=True, seed=21), net(lr=lr, eps_std=0.6, reverse=True, eps=eps)]
+        assert len(net.engines()) == 1
         net.set_streams(2)
         try:
             two = [net(lr=lr, eps_std=0.6, reverse=True, seed=21), net(lr=lr, eps_std=0.6, reverse=True, eps=eps)]
@@ -142,7 +144,35 @@ def test_two_stream_split_equals_the_single_stream_call(name):
             rest = [0, 1, 2, 3, 5]
             assert torch.equal(out[rest], two[0][rest])
         finally:
+            net.set_streams(2)
+
+
+def test_kept_conditional_features_with_the_two_stream_split():
+    """cache_cond=True on a split call: each engine keeps ITS half's features; the split layout is part of the cache key, so a call
+    that is split differently from the one that filled the caches (set_streams in between) refills them instead of reading the
+    other layout's buffers. Outputs equal the uncached single-stream ones bit for bit (tiny net: one kernel schedule)."""
+    cfg, net = _net("SR_8X_tiny", 12, "f16x3")
+    g = torch.Generator().manual_seed(14)
+    lr_a = torch.rand(6, 3, 8, 12, generator=g).cuda()
+    lr_b = torch.rand(6, 3, 8, 12, generator=g).cuda()
+    taus = [0.0, 0.4, 0.9]
+    with torch.no_grad():
+        net.set_streams(1)
+        want_a = [net(lr=lr_a, eps_std=t, reverse=True, seed=70 + i) for i, t in enumerate(taus)]
+        want_b = [net(lr=lr_b, eps_std=t, reverse=True, seed=70 + i) for i, t in enumerate(taus)]
+        net.set_streams(2)
+        try:
+            got = [net(lr=lr_a, eps_std=t, reverse=True, seed=70 + i, cache_cond=True) for i, t in enumerate(taus)]
+            assert len(net.engines()) == 2
+            assert all(torch.equal(a, b) for a, b in zip(want_a, got))
+            # the twin engine now holds lr_a's second half; an UNSPLIT cached call on lr_b, then a split one on lr_b
             net.set_streams(1)
+            assert torch.equal(net(lr=lr_b, eps_std=taus[1], reverse=True, seed=71, cache_cond=True), want_b[1])
+            net.set_streams(2)
+            got_b = [net(lr=lr_b, eps_std=t, reverse=True, seed=70 + i, cache_cond=True) for i, t in enumerate(taus)]
+            assert all(torch.equal(a, b) for a, b in zip(want_b, got_b))
+        finally:
+            net.set_streams(2)
 
 
 def test_range_overflow_of_one_sample_reruns_that_sample_only():
