@@ -87,8 +87,17 @@ def test_default_precision_and_policies(monkeypatch):
     cfg = preset("SR_4X_tiny")
     monkeypatch.delenv("HCFLOW_PRECISION", raising=False)
     monkeypatch.delenv("HCFLOW_RANGE_CHECK", raising=False)
+    monkeypatch.delenv("HCFLOW_STREAMS", raising=False)
     net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
     assert net._precision[0] == "f16x3" and net._range_check[0] == "sync"
+    # batched inference calls run as two half batches on the process' two side streams by default; B < 4 never splits
+    assert net._nstreams[0] == 2 and net._parts(None, 0, None, 3) is None
+    assert net.set_streams(1)._parts(None, 0, None, 16) is None
+    monkeypatch.setenv("HCFLOW_STREAMS", "1")
+    assert HCFlowNet_SR(opt=cfg.to_opt(), step=0)._nstreams[0] == 1
+    # the per-call parameter stamp is two flat lists of ints (no per-parameter containers for the garbage collector)
+    st = net._stamp_of(net._tensor_list())
+    assert len(st) == 2 and all(isinstance(v, int) for v in st[0] + st[1]) and len(st[0]) == len(net._tensors())
     monkeypatch.setenv("HCFLOW_PRECISION", "exact")
     assert HCFlowNet_SR(opt=cfg.to_opt(), step=0)._precision[0] == "exact"
     net.set_precision("exact").set_range_check("lazy")
