@@ -399,6 +399,11 @@ def _enqueue_pool():
     return _POOL[0]
 
 
+class _StaleParameters(Exception):
+    """A call that was enqueued before its parameter stamp was verified (``_engine_for(defer=True)``) found the parameters changed:
+    the enqueued pass has been drained and the call is redone on the checked path."""
+
+
 def _split_threaded(lr_pixels: int) -> bool:
     """Second half of a split call enqueued by the helper thread? Default: yes (Face x8 at LR 20 x 20: 1 542 against 1 403 img/s with
     one thread enqueueing both halves, 1 416 unsplit; the -25 % once measured for this case was a garbage-collection pause inside
@@ -561,9 +566,16 @@ class _EngineModule(nn.Module):
         return self
 
     # -- engine management
-    def _engine_for(self, device: torch.device, slot: int = 0):
+    def _engine_for(self, device: torch.device, slot: int = 0, same_call: bool = False, defer: bool = False):
         """The engine of ``device`` (slot 0), or its twin (slot 1: the second half batch of a split inference call runs on it,
-        beside slot 0's, on a second HIP stream -- its own workspace and packs, the same parameter tensors)."""
+        beside slot 0's, on a second HIP stream -- its own workspace and packs, the same parameter tensors).
+
+        ``defer`` (eval-mode inference calls): the walk over the 1 500-1 900 parameter tensors that tells whether the packs are
+        current (~1 ms of Python) is GPU idle time when it runs in front of a call's first launch -- under the default `sync`
+        policy every call starts on an idle GPU. An engine whose last check found the parameters unchanged is handed out
+        unchecked; ``_run_checked`` verifies the stamp AFTER the pass is enqueued, while the GPU runs it, and on a mismatch drains the
+        pass (it only wrote the workspace and the output) and has the call redone on the checked path (``_StaleParameters``). The
+        pass never reads the caller's parameter tensors, only the engine's packs."""
         if device.type != "cuda":
             raise _lib.HcfError(
                 "hcflow_amd runs on MI355X only: move the module and its inputs to a GPU "
@@ -575,8 +587,25 @@ class _EngineModule(nn.Module):
             ent = {"engine": _lib.Engine(self.cfg), "stamp": None}
             ent["engine"].set_precision(self._precision[0])
             self._engines[key] = ent
-        tens = self._tensor_list()
-        stamp = self._stamp_of(tens)
+        if slot == 0:
+            self.__dict__["_call_stamp"] = None
+            self.__dict__["_deferred"] = None
+        if (defer and slot == 0) or (same_call and self.__dict__.get("_deferred") is not None):
+            if ent["stamp"] is not None and ent.get("stable"):
+                if slot == 0:
+                    self.__dict__["_deferred"] = []
+                self.__dict__["_deferred"].append(ent)
+                return ent["engine"], idx
+        # (same_call: the twin engine of a split call is looked up right after the primary one -- the ~1 ms walk over the 1 500-1 900
+        #  parameter tensors is not repeated)
+        memo = self.__dict__.get("_call_stamp") if same_call else None
+        if memo is not None:
+            tens, stamp = memo
+        else:
+            tens = self._tensor_list()
+            stamp = self._stamp_of(tens)
+            self.__dict__["_call_stamp"] = (tens, stamp)
+        ent["stable"] = ent["stamp"] == stamp        # unchanged since the last check: the next eval-mode call may defer its own
         if ent["stamp"] != stamp:
             named = list(zip(self._spec_keys, tens))
             eng = ent["engine"]
@@ -654,6 +683,19 @@ class _EngineModule(nn.Module):
                 _lib.check(rc1, e1.handle, what)
                 for _, _, _, st_ in parts:
                     cur.wait_stream(st_)                          # joined: the output is complete on the caller's stream
+            deferred = self.__dict__.get("_deferred")
+            if deferred:
+                # the stamp check this call skipped in front of its first launch (_engine_for(defer=True)), now beside the running pass
+                self.__dict__["_deferred"] = None
+                memo = self.__dict__.get("_call_stamp")
+                stamp = memo[1] if memo is not None else self._stamp_of(self._tensor_list())
+                if any(ent["stamp"] != stamp for ent in deferred):
+                    for ent in deferred:
+                        ent["stable"] = False
+                    cur.synchronize()                             # the stale pass only wrote the workspace and `out`
+                    for e_, _, _, _ in parts:
+                        e_.check_range_samples()                  # (whatever it flagged is dropped with it)
+                    raise _StaleParameters()
             if self._precision[0] != "f16x3" or self._range_check[0] != "sync":
                 return
             flagged, any_over = [], False
@@ -680,7 +722,7 @@ class _EngineModule(nn.Module):
         """How a batch of B samples is spread over the device's engines / streams."""
         if not allow or self._nstreams[0] < 2 or B < 4:
             return None
-        eng2, _ = self._engine_for(dev, slot=1)
+        eng2, _ = self._engine_for(dev, slot=1, same_call=True)
         h1 = B - B // 2
         # NEITHER half on the caller's stream: that is normally the process' default (null) stream, whose launches do not run beside
         # another stream's (measured: the halves serialise, 140 against 130 ms per step; on two side streams they overlap)
@@ -790,8 +832,18 @@ class _EngineModule(nn.Module):
             lr_t = lr.to(device=dev, dtype=torch.float32).contiguous()          # keeps the autograd link to the caller's lr
             return _SRReverseStep.apply(self, lr_t, tau, seed, bool(clamp), eps, *self._params())
         self._check_inference(reverse=True)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
+        if not self.training:
+            try:
+                return self._inverse_pass(lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer=True)
+            except _StaleParameters:
+                pass                                               # parameters changed since the last call: the checked path
+        return self._inverse_pass(lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer=False)
+
+    def _inverse_pass(self, lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer):
         dev = self._device()
-        eng, idx = self._engine_for(dev)
+        eng, idx = self._engine_for(dev, defer=defer)
         lr_in = lr
         lr = self._prep(lr, dev)
         B, c, h, w = lr.shape
@@ -815,8 +867,6 @@ class _EngineModule(nn.Module):
                 keep.append(e)
                 keep_at[i] = e
                 arr[i] = e.data_ptr()
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
         tau = 0.0 if eps_std is None else float(eps_std)
         flags = 0 if clamp else _lib.FLAG_NO_CLAMP
         if self._range_check[0] == "off":
@@ -958,8 +1008,16 @@ class HCFlowNet_Rescaling(_EngineModule):
                     self.normal_flow_diracLR(hr)
             return _RescaleForwardStep.apply(self, self._prep(hr, dev), bool(clamp), *self._params())
         self._check_inference()
+        if not self.training:
+            try:
+                return self._forward_pass(hr, clamp, defer=True)
+            except _StaleParameters:
+                pass                                               # parameters changed since the last call: the checked path
+        return self._forward_pass(hr, clamp, defer=False)
+
+    def _forward_pass(self, hr, clamp, defer):
         dev = self._device()
-        eng, idx = self._engine_for(dev)
+        eng, idx = self._engine_for(dev, defer=defer)
         self._cond_key.pop(idx, None)
         hr = self._prep(hr, dev)
         B, c, H, W = hr.shape
@@ -975,7 +1033,7 @@ class HCFlowNet_Rescaling(_EngineModule):
         self._run_checked(eng, idx, lambda e_, lo, hi, stream: e_.lib.hcf_forward_rescale(
             e_.handle, hr[lo:hi].data_ptr(), out_lr[lo:hi].data_ptr(), z1[lo:hi].data_ptr(), z2[lo:hi].data_ptr(), hi - lo, H, W,
             fl, stream), "hcf_forward_rescale", batch=B, parts=self._parts(dev, idx, eng, B, allow=not pend),
-            threaded=H * W >= 65536)
+            threaded=_split_threaded(H * W))
         self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 

@@ -147,6 +147,45 @@ def test_two_stream_split_equals_the_single_stream_call(name):
             net.set_streams(2)
 
 
+@pytest.mark.parametrize("name", ["SR_4X_tiny", "Rescaling_4X_tiny"])
+def test_deferred_parameter_check_redoes_a_call_whose_parameters_changed(name):
+    """Eval-mode inference calls skip the ~1 ms parameter walk in front of their first launch once a check has found the parameters
+    unchanged, and verify the stamp while the GPU runs the pass (arch.py: _engine_for(defer=True)). A parameter written in place
+    between two calls must still be picked up: the stale pass is drained and the call redone on the checked path."""
+    cfg, net = _net(name, 11, "f16x3")
+    g = torch.Generator().manual_seed(9)
+    lr = torch.rand(6, 3, 12, 16, generator=g).cuda()
+    hr = torch.rand(6, 3, 48, 64, generator=g).cuda()
+
+    def call():
+        out = [net(lr=lr, eps_std=0.5, reverse=True, seed=3)]
+        if not cfg.sr:
+            out += list(net(hr=hr, reverse=False))
+        return out
+
+    def same(a, b):
+        return all(torch.equal(x, y) for x, y in zip(a, b))
+    with torch.no_grad():
+        a = [call() for _ in range(3)]
+        ents = list(net._engines.values())
+        assert len(ents) == 2 and all(e.get("stable") for e in ents)         # (the split's twin engine included)
+        assert same(a[0], a[1]) and same(a[1], a[2])
+        for p in net.parameters():
+            if p.dim() == 4 and p.shape[1] > 1 and float(p.abs().max()) > 0:
+                p.mul_(1.05)
+                break
+        b = call()                                   # enqueued unchecked, found stale, redone
+        assert not same(b, a[0])
+        if cfg.sr:                                   # (the rescaling case's second call of `call()` is a checked, unchanged one already)
+            assert not any(e.get("stable") for e in ents)
+        c = call()                                   # checked: unchanged
+        d = call()                                   # deferred again
+        assert all(e.get("stable") for e in ents) and same(b, c) and same(c, d)
+        net.invalidate()                             # the full host path packs the same weights
+        e_ = call()
+        assert all(float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())) for x, y in zip(e_, b))
+
+
 def test_kept_conditional_features_with_the_two_stream_split():
     """cache_cond=True on a split call: each engine keeps ITS half's features; the split layout is part of the cache key, so a call
     that is split differently from the one that filled the caches (set_streams in between) refills them instead of reading the
