@@ -153,6 +153,7 @@ def test_deferred_parameter_check_redoes_a_call_whose_parameters_changed(name):
     unchanged, and verify the stamp while the GPU runs the pass (arch.py: _engine_for(defer=True)). A parameter written in place
     between two calls must still be picked up: the stale pass is drained and the call redone on the checked path."""
     cfg, net = _net(name, 11, "f16x3")
+    net.set_streams(2)                               # (the default; explicit so that the test also holds under HCFLOW_STREAMS=1)
     g = torch.Generator().manual_seed(9)
     lr = torch.rand(6, 3, 12, 16, generator=g).cuda()
     hr = torch.rand(6, 3, 48, 64, generator=g).cuda()
