@@ -658,3 +658,53 @@ def test_training_step_on_a_side_stream_equals_the_default_stream():
         assert n0 == n1
         for a, b in zip(g0, g1):
             assert np.array_equal(a, b)
+
+
+def test_training_steps_between_split_inference_calls_keep_their_gradients():
+    """The split inference calls and the training pass share the process' two side streams (hcf_aux_stream: half batches there,
+    weight gradients / conditional-feature gradients here). Training steps with split sampling calls of another module in between
+    (a validation loop inside a training loop, HCFlow_SR_model.py:209-262 between :184-205) give the gradients of the undisturbed
+    steps bit for bit."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR, optim
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, spec_grads
+    cfg = preset("SR_4X_tiny")
+    g = torch.Generator().manual_seed(43)
+    hr = torch.rand(4, 3, 64, 96, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    lr_val = torch.rand(6, 3, 12, 16, generator=g).cuda()
+
+    def build(train):
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(cached_params("SR_4X_tiny", 11), strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to("cuda:0")
+        return net.train() if train else net.eval()
+    res, samples = [], []
+    for disturb in (False, True):
+        net, val = build(True), build(False).set_streams(2)
+        opt = optim.Adam([q for q in net.parameters() if q.requires_grad], lr=1e-6)
+        steps = []
+        for it in range(3):
+            if disturb:
+                with torch.no_grad():
+                    samples.append(val(lr=lr_val, eps_std=0.7, reverse=True, seed=5))     # split: two halves on the side streams
+            opt.zero_grad(set_to_none=True)
+            _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+            nll.backward()
+            grads = spec_grads(net, cfg)
+            opt.step()
+            steps.append((float(nll.detach()), grads))
+        torch.cuda.synchronize()
+        res.append(steps)
+        if disturb:
+            assert len(val.engines()) == 2
+    for (n0, g0), (n1, g1) in zip(res[0], res[1]):
+        assert n0 == n1
+        for a, b in zip(g0, g1):
+            assert np.array_equal(a, b)
+    assert all(torch.equal(samples[0], s) for s in samples[1:])

@@ -187,6 +187,23 @@ def test_deferred_parameter_check_redoes_a_call_whose_parameters_changed(name):
         assert all(float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())) for x, y in zip(e_, b))
 
 
+def test_split_with_and_without_the_helper_thread_gives_the_same_samples(monkeypatch):
+    """HCF_SPLIT_THREADED=0 enqueues both halves of a split call from the calling thread, the default hands the second half to a
+    helper thread: same launches on the same two streams, same outputs."""
+    cfg, net = _net("SR_8X_tiny", 12, "f16x3")
+    net.set_streams(2)
+    g = torch.Generator().manual_seed(15)
+    lr = torch.rand(7, 3, 8, 12, generator=g).cuda()
+    with torch.no_grad():
+        monkeypatch.setenv("HCF_SPLIT_THREADED", "1")
+        a = [net(lr=lr, eps_std=0.6, reverse=True, seed=30 + i) for i in range(3)]
+        monkeypatch.setenv("HCF_SPLIT_THREADED", "0")
+        b = [net(lr=lr, eps_std=0.6, reverse=True, seed=30 + i) for i in range(3)]
+        net.set_streams(1)
+        c = [net(lr=lr, eps_std=0.6, reverse=True, seed=30 + i) for i in range(3)]
+    assert all(torch.equal(x, y) and torch.equal(y, z) for x, y, z in zip(a, b, c))
+
+
 def test_kept_conditional_features_with_the_two_stream_split():
     """cache_cond=True on a split call: each engine keeps ITS half's features; the split layout is part of the cache key, so a call
     that is split differently from the one that filled the caches (set_streams in between) refills them instead of reading the
