@@ -138,7 +138,7 @@ __device__ __forceinline__ gfptr uniform_ptr(const float* p) {
 // (B = [b_lo ; 0]) -- 2/3 of the matrix work of the 32-wide tile (4 half-size MFMAs per 32 pixels and tap instead of 3 full-size
 // ones), same pack, same LDS images.
 template <int NTB, bool VEC, bool UP, bool FUSE2 = false, int TAILC = 0, int TH = 8, bool SCALED = false, bool K1 = false, bool N16 = false>
-__global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? 3 : 2)) void conv_f16x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1) ? 4 : 2) : ((NTB == 1) ? (N16 ? 4 : 3) : 2)) void conv_f16x3_kernel(const ConvArgs a) {
   static_assert(!(FUSE2 && TAILC), "one fused epilogue at a time");
   static_assert(!N16 || (NTB == 1 && TAILC > 0 && (TH == 8 || TH == 4)), "the 16-wide channel tile is built for the fused-tail variants");
   static_assert(!SCALED || (!FUSE2 && TAILC == 0), "input scaling is for the plain variants");
@@ -162,9 +162,14 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
   constexpr int NPAD = NTB * 32;
   constexpr int MT = (TH == 4) ? NTB : 2 * NTB;     // 32-pixel row tiles per wave
   constexpr int A_BYTES = HP * REC;
-  constexpr int BHALF = NPAD * 16;                  // bytes of one (tap, plane, k-half): n x 8 halves
+  // N16: only the first 16 of the pack's 32 channel columns are staged (the launcher guarantees <= 16 output channels): half the
+  // weight tile in LDS (36.4 instead of 45.6 KB per block: FOUR blocks per CU instead of three -- the launch is bound by the
+  // bytes its blocks keep in flight, profiles/r05_notes.md section 5) and half the weight traffic from L2
+  constexpr int NB = N16 ? 16 : NPAD;               // channel columns of the weight tile kept in LDS
+  constexpr int BHALF = NB * 16;                    // bytes of one (tap, plane, k-half): n x 8 halves
   constexpr int B_BYTES = TAPS * 2 * 2 * BHALF;     // per chunk
   constexpr int BV = B_BYTES / 16;                  // float4 units
+  constexpr int BVG = TAPS * 2 * 2 * NPAD;          // float4 units of one chunk in the PACK (all 32 * NTB columns)
   constexpr int BSLOT = (BV + NTHR - 1) / NTHR;
   constexpr int F2_BYTES = FUSE2 ? (TH * TW) * 4 * 64 : 0;      // [256 px][4 k-chunks][16 hi | 16 lo]
   constexpr int HCS = (NTB == 1) ? 33 : 49;                      // odd row stride of the h tile (floats): conflict-free
@@ -230,6 +235,7 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
   const int n0 = __builtin_amdgcn_readfirstlane(a.src[0].n), n1 = __builtin_amdgcn_readfirstlane(a.src[1].n),
             n2 = __builtin_amdgcn_readfirstlane(a.src[2].n);
   const gf4ptr wq = (gf4ptr)uniform_ptr(a.wpack) + tid;   // this thread's float4 lane of the weight stream
+  const gf4ptr wq0 = (gf4ptr)uniform_ptr(a.wpack);        // (N16: LDS unit q = pack unit (q >> 4) * 32 + (q & 15): columns 0..15 of each block)
   const gfptr zpage = uniform_ptr(a.zeros);
   float in_s = 1.f, out_s = 1.f;                 // SCALED: x * in_s lands in [2^9, 2^10] at the tensor's max |x|
   int in_max_bits = 0;
@@ -278,7 +284,8 @@ __global__ __launch_bounds__((TH == 4) ? 256 : 32 * TH, (TH == 16) ? ((NTB == 1)
     stg_valid = valid;                                                                            \
     _Pragma("unroll") for (int s = 0; s < BSLOT; ++s) {                                           \
       const int q = tid + NTHR * s;                                                               \
-      stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? NTHR * s : 0)];                              \
+      if (N16) stb[s] = wq0[(size_t)(CHUNK) * BVG + ((q < BV) ? (((q >> 4) << 5) | (q & 15)) : 0)];  \
+      else stb[s] = wq[(size_t)(CHUNK) * BV + ((q < BV) ? NTHR * s : 0)];                         \
     }                                                                                             \
   }
   // split one staged slot in registers (VALU only): stg[s] <- {hi.xy, hi.zw, lo.xy, lo.zw} as packed halves.
