@@ -542,10 +542,17 @@ def train_workload(args, dev, world, rank):
 
         def one(i):
             keep["nll"] = train_step(ddp, hr, lr, opt, clip, 100.0)
-        for i in range(max(2, args.warmup)):                          # >= 2: step 1 builds plans / buckets, step 2 sees a device refresh
-            one(i)
-        with PowerSampler(int(os.environ.get("LOCAL_RANK", "0"))) as psamp, quiet_gc():
-            dt = timed_region(one, args.steps, first=args.warmup)
+        # HCF_BENCH_SIDE_STREAM=1 (experiment knob): the whole loop inside torch.cuda.stream(side) instead of the process' default stream
+        side_ctx = contextlib.nullcontext()
+        if os.environ.get("HCF_BENCH_SIDE_STREAM"):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            side_ctx = torch.cuda.stream(side)
+        with side_ctx:
+            for i in range(max(2, args.warmup)):                      # >= 2: step 1 builds plans / buckets, step 2 sees a device refresh
+                one(i)
+            with PowerSampler(int(os.environ.get("LOCAL_RANK", "0"))) as psamp, quiet_gc():
+                dt = timed_region(one, args.steps, first=args.warmup)
         power[native] = psamp.block()
         nll = float(keep["nll"])
         assert nll == nll, "NLL is NaN"

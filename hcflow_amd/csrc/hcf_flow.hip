@@ -243,23 +243,26 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, u
 // ---- Gaussian prior ---------------------------------------------------------------------------
 // sample: a = mean + exp(logs) * eps,  (mean, s) = h[0::2], h[1::2]   (Basic.py:96-101,
 // ConditionalFlow.py:61-64 SR, :88-91 rescaling with logs = 0.318 atan(2 s))
+// One thread per (pixel, channel), channel fastest: consecutive lanes read consecutive (mean, s) pairs and write consecutive
+// outputs of the NHWC records (the one-thread-per-pixel form walked its pixel's channels in a loop: every load of a wave touched 64
+// records, and the Philox / Box-Muller chains of a pixel's 6-21 channels ran back to back in one lane: 217 us for 8.6 M elements).
+// Same arithmetic per element, same Philox counter (the NCHW element index): bit-identical draws.
 __global__ __launch_bounds__(256) void gauss_sample_kernel(const GaussArgs a) {
   const int hw = a.H * a.W;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= hw) return;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)hw * a.C) return;
   const int b = blockIdx.y;
+  const int i = (int)(t / a.C), c = (int)(t - (long long)i * a.C);
   const size_t pix = (size_t)b * hw + i;
   const float* hp = a.h.p + pix * a.h.cs + a.h.c0;
   float* op = a.out.p + pix * a.out.cs + a.out.c0;
-  for (int c = 0; c < a.C; ++c) {
-    const float mean = hp[2 * c], s = hp[2 * c + 1];
-    const float logs = a.rescale ? logscale_of(s) : s;
-    const size_t e = ((size_t)b * a.C + c) * hw + i;           // NCHW element index
-    float eps;
-    if (a.eps) eps = a.eps[e];
-    else eps = (a.tau == 0.f) ? 0.f : a.tau * philox_normal(a.seed, a.offset, e + (size_t)a.b0 * a.C * hw);
-    op[c] = mean + expf(logs) * eps;
-  }
+  const float mean = hp[2 * c], s = hp[2 * c + 1];
+  const float logs = a.rescale ? logscale_of(s) : s;
+  const size_t e = ((size_t)b * a.C + c) * hw + i;           // NCHW element index
+  float eps;
+  if (a.eps) eps = a.eps[e];
+  else eps = (a.tau == 0.f) ? 0.f : a.tau * philox_normal(a.seed, a.offset, e + (size_t)a.b0 * a.C * hw);
+  op[c] = mean + expf(logs) * eps;
 }
 
 // logp: sum -0.5 (2 logs + (x - mean)^2 / exp(2 logs) + ln 2pi)   (Basic.py:78-94)
@@ -298,9 +301,12 @@ __global__ __launch_bounds__(256) void gauss_encode_kernel(const GaussArgs a) {
 }
 
 static inline dim3 pix_grid(int B, int H, int W) { return dim3((unsigned)((H * W + 255) / 256), (unsigned)B); }
+static inline dim3 elem_grid(int B, long long per_sample) { return dim3((unsigned)((per_sample + 255) / 256), (unsigned)B); }
 
 int launch_gauss_sample(const GaussArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(gauss_sample_kernel, pix_grid(a.B, a.H, a.W), dim3(256), 0, st, a);
+  const long long n = (long long)a.H * a.W * a.C;
+  if (n <= 0 || (n + 255) / 256 > 0x7fffffffLL) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)a.B), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 int launch_gauss_logp(const GaussArgs& a, hipStream_t st) {
@@ -368,24 +374,22 @@ __global__ __launch_bounds__(256) void squeeze_kernel(View in, View out, int C, 
 }
 
 // in [B,H,W,C4] -> out [B,2H,2W,C4/4]; one thread per INPUT pixel
+// one thread per OUTPUT element (pixel, channel), channel fastest: consecutive lanes write consecutive floats of the NHWC records
+// (the one-thread-per-input-pixel form looped over 4 C scattered stores per lane); same index map / same Haar sum order
 __global__ __launch_bounds__(256) void unsqueeze_kernel(View in, View out, int C4, int H, int W, int haar) {
-  const int hw = H * W, C = C4 >> 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= hw) return;
-  const int b = blockIdx.y, h = i / W, w = i - h * W;
-  const float* ip = in.p + ((size_t)b * hw + i) * in.cs + in.c0;
-#pragma unroll
-  for (int di = 0; di < 2; ++di)
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj) {
-      float* op = out.p + ((size_t)((size_t)b * 2 * H + 2 * h + di) * (2 * W) + 2 * w + dj) * out.cs + out.c0;
-      for (int c = 0; c < C; ++c) {
-        if (!haar) op[c] = ip[c * 4 + di * 2 + dj];
-        else
-          op[c] = ((ip[c] * haar_sign(0, di, dj) + ip[C + c] * haar_sign(1, di, dj)) + ip[2 * C + c] * haar_sign(2, di, dj)) +
-                  ip[3 * C + c] * haar_sign(3, di, dj);
-      }
-    }
+  const int C = C4 >> 2, W2 = 2 * W;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)4 * H * W * C) return;
+  const int b = blockIdx.y;
+  const int o = (int)(t / C), c = (int)(t - (long long)o * C);        // output pixel (of this sample), channel
+  const int oy = o / W2, ox = o - oy * W2;
+  const int h = oy >> 1, di = oy & 1, w = ox >> 1, dj = ox & 1;
+  const float* ip = in.p + ((size_t)b * H * W + (size_t)h * W + w) * in.cs + in.c0;
+  float* op = out.p + ((size_t)b * 4 * H * W + o) * out.cs + out.c0;
+  if (!haar) op[c] = ip[c * 4 + di * 2 + dj];
+  else
+    op[c] = ((ip[c] * haar_sign(0, di, dj) + ip[C + c] * haar_sign(1, di, dj)) + ip[2 * C + c] * haar_sign(2, di, dj)) +
+            ip[3 * C + c] * haar_sign(3, di, dj);
 }
 
 // NCHW (+ dequantisation noise) -> squeeze/haar -> NHWC   (HCFlowNet_SR_arch.py:52 + first layer)
@@ -442,13 +446,13 @@ __global__ __launch_bounds__(256) void unsqueeze_nchw_kernel(View in, float* dst
   }
 }
 
+// one thread per (pixel, channel), channel fastest (coalesced within the NHWC records)
 __global__ __launch_bounds__(256) void copy_view_kernel(View in, View out, int hw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= hw) return;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)hw * in.n) return;
+  const int i = (int)(t / in.n), c = (int)(t - (long long)i * in.n);
   const size_t pix = (size_t)blockIdx.y * hw + i;
-  const float* ip = in.p + pix * in.cs + in.c0;
-  float* op = out.p + pix * out.cs + out.c0;
-  for (int c = 0; c < in.n; ++c) op[c] = ip[c];
+  out.p[pix * out.cs + out.c0 + c] = in.p[pix * in.cs + in.c0 + c];
 }
 
 // z1 of a coupling net as a tensor of its own, zero padded to whole 16-channel chunks (out.n = 16 / 32 / 48 at stride out.cs): the
@@ -588,7 +592,7 @@ int launch_squeeze(View in, View out, int B, int C, int H, int W, hipStream_t st
 }
 int launch_unsqueeze(View in, View out, int B, int C4, int H, int W, hipStream_t st) {
   if (C4 & 3) return HCF_ERR_SHAPE;
-  hipLaunchKernelGGL(unsqueeze_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, C4, H, W, 0);
+  hipLaunchKernelGGL(unsqueeze_kernel, elem_grid(B, (long long)H * W * C4), dim3(256), 0, st, in, out, C4, H, W, 0);
   HCF_RET();
 }
 int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t st) {
@@ -598,7 +602,7 @@ int launch_haar_fwd(View in, View out, int B, int C, int H, int W, hipStream_t s
 }
 int launch_haar_inv(View in, View out, int B, int C4, int H, int W, hipStream_t st) {
   if (C4 & 3) return HCF_ERR_SHAPE;
-  hipLaunchKernelGGL(unsqueeze_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, C4, H, W, 1);
+  hipLaunchKernelGGL(unsqueeze_kernel, elem_grid(B, (long long)H * W * C4), dim3(256), 0, st, in, out, C4, H, W, 1);
   HCF_RET();
 }
 int launch_nchw_squeeze(const float* src, const float* noise, float quant, View out, int B, int C, int H, int W,
@@ -614,7 +618,8 @@ int launch_unsqueeze_nchw(View in, float* dst, int B, int C4, int H, int W, int 
   HCF_RET();
 }
 int launch_copy_view(View in, View out, int B, int H, int W, hipStream_t st) {
-  hipLaunchKernelGGL(copy_view_kernel, pix_grid(B, H, W), dim3(256), 0, st, in, out, H * W);
+  if (in.n < 1) return HCF_ERR_ARG;
+  hipLaunchKernelGGL(copy_view_kernel, elem_grid(B, (long long)H * W * in.n), dim3(256), 0, st, in, out, H * W);
   HCF_RET();
 }
 int launch_copy_pad(View in, View out, int B, int H, int W, hipStream_t st) {
