@@ -672,6 +672,8 @@ class _EngineModule(nn.Module):
                 for _, _, _, st_ in parts:
                     st_.wait_stream(cur)                          # the inputs were produced on the caller's stream
                 (e0, lo0, hi0, s0), (e1, lo1, hi1, s1) = parts
+                if threaded and torch.cuda.is_current_stream_capturing():
+                    threaded = False                              # a capturing stream's launches stay on the capturing thread
                 if threaded:
                     fut = _enqueue_pool().submit(call, e1, lo1, hi1, C.c_void_p(s1.cuda_stream))
                     rc0 = call(e0, lo0, hi0, C.c_void_p(s0.cuda_stream))

@@ -258,14 +258,17 @@ def test_range_overflow_of_one_sample_reruns_that_sample_only():
             assert not ok and slots == 0
 
 
+@pytest.mark.parametrize("batch", [2, 6])
 @pytest.mark.parametrize("precision", ["exact", "f16x3"])
-def test_steady_state_inverse_only_enqueues_and_can_be_graph_captured(precision):
+def test_steady_state_inverse_only_enqueues_and_can_be_graph_captured(precision, batch):
     """With the plan cached and the range flag read back asynchronously a steady-state call contains no allocation and no
-    host-device synchronisation: the whole pass can be captured into a HIP graph and replayed (bit-identical to eager)."""
+    host-device synchronisation: the whole pass can be captured into a HIP graph and replayed (bit-identical to eager). batch 6:
+    the call takes the two-stream split -- under capture both halves are enqueued by the capturing thread (fork / join by events:
+    two branches of the graph), no helper thread."""
     cfg, net = _net("SR_4X_tiny", 11, precision)
-    net.set_range_check("lazy")
+    net.set_range_check("lazy").set_streams(2)
     g = torch.Generator().manual_seed(6)
-    lr = torch.rand(2, 3, 16, 16, generator=g).cuda()
+    lr = torch.rand(batch, 3, 16, 16, generator=g).cuda()
     with torch.no_grad():
         eager = net(lr=lr, eps_std=0.8, reverse=True, seed=77)        # also sizes the workspace
         torch.cuda.synchronize()
@@ -281,7 +284,7 @@ def test_steady_state_inverse_only_enqueues_and_can_be_graph_captured(precision)
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, eager)
-        lr.copy_(torch.rand(2, 3, 16, 16, generator=g))               # new LR contents, same graph
+        lr.copy_(torch.rand(batch, 3, 16, 16, generator=g))           # new LR contents, same graph
         graph.replay()
         torch.cuda.synchronize()
         again = net(lr=lr, eps_std=0.8, reverse=True, seed=77)
