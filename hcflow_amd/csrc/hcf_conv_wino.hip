@@ -155,8 +155,10 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   // what this one read and wrote, and the part touched last is still in the MALL when the walk starts there (profiles/r05_notes.md section 9).
   const char* const rev_env = getenv("HCF_WINO_REV");                 // (read per launch: tests switch it inside one process)
   const int rev_mode = rev_env ? atoi(rev_env) : 1;
-  static std::atomic<unsigned> rev_flip{0};
-  w.rev = rev_mode ? (int)(rev_flip.fetch_add(1, std::memory_order_relaxed) & 1u) : 0;
+  // (per enqueuing THREAD: the two half batches of a split call are enqueued by two threads, one engine each -- a process-wide
+  //  counter would hand one of them the even and the other the odd numbers, i.e. no alternation inside either stream)
+  static thread_local unsigned rev_flip = 0;
+  w.rev = rev_mode ? (int)(rev_flip++ & 1u) : 0;
   const int ncu = wino_ncu();
   // One persistent block per CU walks units of 16 x 32 pixels x 32 channels (8 x 32 x 64 for 64 output channels): a grid of a few rounds with a ragged last one
   // (below 75 % occupancy of the rounds) loses what the kernel gains -- the direct kernel takes those. (The 160 x 160 level of
