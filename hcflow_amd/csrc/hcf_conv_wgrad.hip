@@ -237,16 +237,33 @@ __device__ __forceinline__ void split_hl_g(const f32x4 v, u32x2& h, u32x2& l, u3
   hs = u32x2{S0, S1};
 }
 
+// G split for the double-buffered form: hi and lo only
+__device__ __forceinline__ void split_hl_g2(const f32x4 v, u32x2& h, u32x2& l) {
+  const f16x2 h01 = {(_Float16)v.x, (_Float16)v.y}, h23 = {(_Float16)v.z, (_Float16)v.w};
+  const uint32_t H0 = __builtin_bit_cast(uint32_t, h01), H1 = __builtin_bit_cast(uint32_t, h23);
+  uint32_t L0, L1;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L0) : "v"(H0), "v"(v.x));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L0) : "v"(H0), "v"(v.y));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(L1) : "v"(H1), "v"(v.z));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(L1) : "v"(H1), "v"(v.w));
+  h = u32x2{H0, H1};
+  l = u32x2{L0, L1};
+}
+
 template <int TAPS> struct Wg16 {
   static constexpr int PAD = (TAPS == 9) ? 1 : 0;
   static constexpr int HH = TH + 2 * PAD, HW = TW + 2 * PAD, HP = HH * HW;
   static constexpr int XB = HP * 64, GB = TH * TW * 64;          // bytes of one f16 plane of the X halo / the G tile
   static constexpr int LDS_BYTES = 2 * XB + 3 * GB;              // 92 672 (3x3) / 81 920 (1x1): X hi, lo'; G hi, lo, hi * 2^-11
+  // double-buffered form (the default): two buffers of {X hi, X lo', G hi, G lo}; g_hi * 2^-11 is formed in registers from the
+  // g_hi fragment (four v_pk_mul_f16 per 16 pixels), so its plane is gone and two buffers fit one CU's 160 KB
+  static constexpr int BUF_BYTES = 2 * XB + 2 * GB;              // 76 288 (3x3) / 65 536 (1x1)
+  static constexpr int LDS2_BYTES = 2 * BUF_BYTES;               // 152 576 (3x3) / 131 072 (1x1)
 };
 
 // (bxi, byi, bzi) = (pixel slice, input-channel block, output-channel block) in a grid of (., gdy, gdz): the block coordinates of
 // the one-conv launch, or decoded from a linear block number by the batched launch
-template <int TAPS, bool VEC>
+template <int TAPS, bool VEC, int DB>
 __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int bxi, const int byi, const int bzi, const int gdy, const int gdz) {
   typedef Wg16<TAPS> C;
   constexpr int PAD = C::PAD, HW = C::HW, HP = C::HP, XB = C::XB, GB = C::GB;
@@ -359,6 +376,219 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
   const char* const gw = gh + lofs + wave * (TW * 64);
 
   const int t0 = bxi * a.tpb, t1 = min(ntiles, t0 + a.tpb);
+  if constexpr (DB == 2) {
+    // ---- double-buffered, interleaved form (the default): tile i's MFMAs read LDS buffer i & 1 while the staging registers of
+    // tile i + 1 (loaded a whole tile earlier) are converted and written to the OTHER buffer ONE SLOT PER TAP, each slot's
+    // register then reloaded with tile i + 2: the convert / ds_write / address / global_load stream of a slot (~40 VALU
+    // instructions) issues in the shadow of that tap's three MFMAs (96 matrix-pipe cycles), one barrier per tile. The
+    // single-buffer form runs barrier, convert + write (all 16 waves of the CU at once, matrix pipe idle), barrier, MFMAs.
+    constexpr int BUFB = C::BUF_BYTES;
+    constexpr int NS = NX + NG, SPP = (NS + 2 * TAPS - 1) / (2 * TAPS);      // staging slots, slots per (step, tap) position
+    int x0n = 0, y0n = 0, btn = 0;                     // tile whose loads are being issued
+#define HCF_WG_COORDS(TILE)                                                                                   \
+    {                                                                                                         \
+      const int txb_ = (TILE) % tiles_x, tyb_ = ((TILE) / tiles_x) % tiles_y;                                 \
+      btn = sw ? 0 : (TILE) / (tiles_x * tiles_y);                                                            \
+      x0n = txb_ * TW; y0n = tyb_ * TH;                                                                       \
+    }
+#define HCF_WG_LOAD_SLOT(SL)                                                                                  \
+    if ((SL) < NX) {                                                                                          \
+      const int s_ = (SL);                                                                                    \
+      const int hp = min((tidl_ + 512 * s_) >> 3, HP - 1);                                                      \
+      const int hy = hp / HW, hxx_ = hp - hy * HW;                                                            \
+      const int y = y0n + hy - PAD;                                                                           \
+      int x = x0n + hxx_ - PAD, b_ = btn;                                                                     \
+      /* strips: virtual column -> (image, column), branch-free (sw is block-uniform: selects, no basic-block split) */ \
+      const int vc_ = min(max(x, 0), svw - 1);                                                                \
+      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                   \
+      const int xr_ = vc_ - bq_ * sw;                                                                         \
+      const bool okx_ = sw ? (x >= 0 && x < svw && xr_ < W) : (x >= 0 && x < W);                              \
+      b_ = sw ? bq_ : b_;                                                                                     \
+      x = sw ? xr_ : x;                                                                                       \
+      mskx = (mskx & ~(1u << s_)) | ((y >= 0 && y < H && okx_) ? (1u << s_) : 0u);                            \
+      const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                           \
+      const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                            \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4x);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, icn - 1)]; v.y = p[min(c4t + 1, icn - 1)];                                           \
+        v.z = p[min(c4t + 2, icn - 1)]; v.w = p[min(c4t + 3, icn - 1)];                                       \
+      }                                                                                                       \
+      rx[s_] = v;                                                                                             \
+    } else if ((SL) < NS) {                                                                                   \
+      const int s_ = (SL) - NX;                                                                               \
+      const int px = (tidl_ + 512 * s_) >> 3;                                                                   \
+      const int y = y0n + (px >> 5);                                                                          \
+      int x = x0n + (px & 31), b_ = btn;                                                                      \
+      const int vc_ = min(x, svw - 1);                                                                        \
+      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                   \
+      const int xr_ = vc_ - bq_ * sw;                                                                         \
+      const bool okx_ = sw ? (x < svw && xr_ < W) : (x < W);                                                  \
+      b_ = sw ? bq_ : b_;                                                                                     \
+      x = sw ? xr_ : x;                                                                                       \
+      mskg = (mskg & ~(1u << s_)) | ((y < H && okx_) ? (1u << s_) : 0u);                                      \
+      const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;       \
+      f32x4 v;                                                                                                \
+      if (VEC) {                                                                                              \
+        v = *reinterpret_cast<const f32x4*>(p + c4g);                                                         \
+      } else {                                                                                                \
+        v.x = p[min(c4t, ocn - 1)]; v.y = p[min(c4t + 1, ocn - 1)];                                           \
+        v.z = p[min(c4t + 2, ocn - 1)]; v.w = p[min(c4t + 3, ocn - 1)];                                       \
+      }                                                                                                       \
+      rg[s_] = v;                                                                                             \
+    }
+#define HCF_WG_STORE_SLOT(SL, BUF)                                                                            \
+    if ((SL) < NX) {                                                                                          \
+      const int s_ = (SL);                                                                                    \
+      char* const xb_ = lds + (BUF) * BUFB;                                                                   \
+      const int q = tidl_ + 512 * s_;                                                                           \
+      f32x4 v = rx[s_];                                                                                       \
+      const bool ok = (mskx >> s_) & 1u;                                                                      \
+      v.x = (ok && vx > 0) ? v.x : 0.f; v.y = (ok && vx > 1) ? v.y : 0.f;                                     \
+      v.z = (ok && vx > 2) ? v.z : 0.f; v.w = (ok && vx > 3) ? v.w : 0.f;                                     \
+      u32x2 h, l;                                                                                             \
+      split_hl_x(v, h, l);                                                                                    \
+      /* threads past the halo's last pixel hold pixel HP - 1's data (their load was clamped to it): they write the same values */ \
+      /* to the same address as its owner instead of branching around the store */                            \
+      const int qp_ = min(q >> 3, HP - 1);                                                                    \
+      *reinterpret_cast<u32x2*>(xb_ + qp_ * 64 + c4t * 2) = h;                                                \
+      *reinterpret_cast<u32x2*>(xb_ + XB + qp_ * 64 + c4t * 2) = l;                                           \
+    } else if ((SL) < NS) {                                                                                   \
+      const int s_ = (SL) - NX;                                                                               \
+      char* const gb_ = lds + (BUF) * BUFB + 2 * XB;                                                          \
+      const int q = tidl_ + 512 * s_;                                                                           \
+      f32x4 v = rg[s_] * g_s;                                                                                 \
+      const bool ok = (mskg >> s_) & 1u;                                                                      \
+      v.x = (ok && vg > 0) ? v.x : 0.f; v.y = (ok && vg > 1) ? v.y : 0.f;                                     \
+      v.z = (ok && vg > 2) ? v.z : 0.f; v.w = (ok && vg > 3) ? v.w : 0.f;                                     \
+      u32x2 h, l;                                                                                             \
+      split_hl_g2(v, h, l);                                                                                   \
+      *reinterpret_cast<u32x2*>(gb_ + (q >> 3) * 64 + c4t * 2) = h;                                           \
+      *reinterpret_cast<u32x2*>(gb_ + GB + (q >> 3) * 64 + c4t * 2) = l;                                      \
+    }
+    // one tile: ST = tile + 1 exists (its registers go to the other buffer), LD = tile + 2 exists (its loads are issued)
+#define HCF_WG_TILE_BODY(ST, LD)                                                                              \
+    {                                                                                                         \
+      const int cur = (tile - t0) & 1;                                                                        \
+      int tidl_ = tid;               /* opaque copy: the slots' pixel coordinates are recomputed per tile (hoisted out of */ \
+      asm volatile("" : "+v"(tidl_));   /* the loop they cost ~20 registers, i.e. spills beside 144 accumulators) */  \
+      const char* const xwc = xw2 + cur * BUFB;                                                               \
+      const char* const gwc = gw2 + cur * BUFB;                                                               \
+      if (LD) HCF_WG_COORDS(tile + 2)                                                                         \
+      _Pragma("unroll") for (int hx = 0; hx < 2; ++hx) {                                                      \
+        const f16x8 bh = tr8(gwc + hx * (16 * 64)), bl = tr8(gwc + GB + hx * (16 * 64));                      \
+        const f16x8 bs = bh * (_Float16)0.00048828125f;        /* g_hi 2^-11 (exact up to f16 denormals) */    \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                                    \
+          const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;                               \
+          const int off = (dy * HW + 16 * hx + dx) * 64;                                                      \
+          const f16x8 ah = tr8(xwc + off), al = tr8(xwc + XB + off);                                          \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);                           \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bs, acc[t], 0, 0, 0);                           \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);                           \
+          if (ST) {                                                                                           \
+            _Pragma("unroll") for (int j_ = 0; j_ < SPP; ++j_) {                                              \
+              const int sl_ = (hx * TAPS + t) * SPP + j_;       /* a constant after unrolling */               \
+              HCF_WG_STORE_SLOT(sl_, cur ^ 1)                                                                 \
+              if (LD) { HCF_WG_LOAD_SLOT(sl_) }                                                               \
+            }                                                                                                 \
+            /* pin the slot to its tap (only MFMAs and LDS reads may cross): left alone, the scheduler hoists every slot's    */ \
+            /* conversion to the top of the tile -- one wait for ALL the staging loads, then the VALU stream, then the MFMAs */ \
+            __builtin_amdgcn_sched_barrier(0x108);                                                            \
+          }                                                                                                   \
+        }                                                                                                     \
+      }                                                                                                       \
+      __syncthreads();                            /* buffer cur read by every wave, buffer cur ^ 1 complete */ \
+    }
+    const char* const xw2 = lds + lofs + wave * (HW * 64);
+    const char* const gw2 = lds + 2 * XB + lofs + wave * (TW * 64);
+    if (t0 < t1) {                                 // prologue: tile t0 into buffer 0, tile t0 + 1 into the registers
+      const int tidl_ = tid;
+      HCF_WG_COORDS(t0)
+      _Pragma("unroll") for (int sl_ = 0; sl_ < NS; ++sl_) { HCF_WG_LOAD_SLOT(sl_) }
+      _Pragma("unroll") for (int sl_ = 0; sl_ < NS; ++sl_) { HCF_WG_STORE_SLOT(sl_, 0) }
+      if (t0 + 1 < t1) {
+        HCF_WG_COORDS(t0 + 1)
+        _Pragma("unroll") for (int sl_ = 0; sl_ < NS; ++sl_) { HCF_WG_LOAD_SLOT(sl_) }
+      }
+    }
+    __syncthreads();
+    int tile = t0;
+    for (; tile + 2 < t1; ++tile) HCF_WG_TILE_BODY(1, 1)
+    if (tile + 1 < t1) {
+      HCF_WG_TILE_BODY(1, 0)
+      ++tile;
+    }
+    if (tile < t1) HCF_WG_TILE_BODY(0, 0)
+#undef HCF_WG_TILE_BODY
+#undef HCF_WG_STORE_SLOT
+#undef HCF_WG_LOAD_SLOT
+#undef HCF_WG_COORDS
+  } else if constexpr (DB == 1) {
+    constexpr int BUFB = C::BUF_BYTES;
+#define HCF_WG_STORE(BUF)                                                                                     \
+    {                                                                                                         \
+      char* const xb_ = lds + (BUF) * BUFB;                                                                   \
+      char* const gb_ = xb_ + 2 * XB;                                                                         \
+      _Pragma("unroll") for (int s_ = 0; s_ < NX; ++s_) {                                                     \
+        const int q = tid + 512 * s_;                                                                         \
+        f32x4 v = rx[s_];                                                                                     \
+        const bool ok = (mskx >> s_) & 1u;                                                                    \
+        v.x = (ok && vx > 0) ? v.x : 0.f; v.y = (ok && vx > 1) ? v.y : 0.f;                                   \
+        v.z = (ok && vx > 2) ? v.z : 0.f; v.w = (ok && vx > 3) ? v.w : 0.f;                                   \
+        u32x2 h, l;                                                                                           \
+        split_hl_x(v, h, l);                                                                                  \
+        if (q < HP * 8) {                                                                                     \
+          *reinterpret_cast<u32x2*>(xb_ + (q >> 3) * 64 + c4t * 2) = h;                                       \
+          *reinterpret_cast<u32x2*>(xb_ + XB + (q >> 3) * 64 + c4t * 2) = l;                                  \
+        }                                                                                                     \
+      }                                                                                                       \
+      _Pragma("unroll") for (int s_ = 0; s_ < NG; ++s_) {                                                     \
+        const int q = tid + 512 * s_;                                                                         \
+        f32x4 v = rg[s_] * g_s;                                                                               \
+        const bool ok = (mskg >> s_) & 1u;                                                                    \
+        v.x = (ok && vg > 0) ? v.x : 0.f; v.y = (ok && vg > 1) ? v.y : 0.f;                                   \
+        v.z = (ok && vg > 2) ? v.z : 0.f; v.w = (ok && vg > 3) ? v.w : 0.f;                                   \
+        u32x2 h, l;                                                                                           \
+        split_hl_g2(v, h, l);                                                                                 \
+        *reinterpret_cast<u32x2*>(gb_ + (q >> 3) * 64 + c4t * 2) = h;                                         \
+        *reinterpret_cast<u32x2*>(gb_ + GB + (q >> 3) * 64 + c4t * 2) = l;                                    \
+      }                                                                                                       \
+    }
+#define HCF_WG_STEP(HX)                                                                                       \
+    {                                                                                                         \
+      const f16x8 bh = tr8(gwc + (HX) * (16 * 64)), bl = tr8(gwc + GB + (HX) * (16 * 64));                    \
+      const f16x8 bs = bh * (_Float16)0.00048828125f;          /* g_hi 2^-11 (exact up to f16 denormals) */    \
+      _Pragma("unroll") for (int t = 0; t < TAPS; ++t) {                                                      \
+        const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;                                 \
+        const int off = (dy * HW + 16 * (HX) + dx) * 64;                                                      \
+        const f16x8 ah = tr8(xwc + off), al = tr8(xwc + XB + off);                                            \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);                             \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bs, acc[t], 0, 0, 0);                             \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);                             \
+      }                                                                                                       \
+    }
+    const char* const xw2 = lds + lofs + wave * (HW * 64);
+    const char* const gw2 = lds + 2 * XB + lofs + wave * (TW * 64);
+    if (t0 < t1) {
+      HCF_WG_LOAD(t0)
+      HCF_WG_STORE(0)
+      if (t0 + 1 < t1) HCF_WG_LOAD(t0 + 1)
+    }
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+      const int cur = (tile - t0) & 1;
+      const char* const xwc = xw2 + cur * BUFB;
+      const char* const gwc = gw2 + cur * BUFB;
+      HCF_WG_STEP(0)
+      if (tile + 1 < t1) HCF_WG_STORE(cur ^ 1)
+      if (tile + 2 < t1) HCF_WG_LOAD(tile + 2)
+      HCF_WG_STEP(1)
+      __syncthreads();                            // buffer cur has been read by every wave, buffer cur ^ 1 is complete
+    }
+#undef HCF_WG_STEP
+#undef HCF_WG_STORE
+  } else {
   if (t0 < t1) HCF_WG_LOAD(t0)
   for (int tile = t0; tile < t1; ++tile) {
     __syncthreads();                              // the previous tile's fragments have been read
@@ -406,6 +636,7 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
       }
     }
   }
+  }
 #undef HCF_WG_LOAD
 
   // ---- fixed-order tree over the eight waves through LDS (two 36 KB slots): ((w0 + w4) + (w2 + w6)) + ((w1 + w5) + (w3 + w7))
@@ -445,16 +676,16 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
 }
 
 
-template <int TAPS, bool VEC>
+template <int TAPS, bool VEC, int DB>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_kernel(const WgradArgs a) {
-  wgrad_f16x3_body<TAPS, VEC>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gridDim.z);
+  wgrad_f16x3_body<TAPS, VEC, DB>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, gridDim.z);
 }
 
 // Several convs' weight gradients as ONE launch (the five convs of a dense block: hcf_engine_train.inc). A one-conv launch is at
 // most one round of one-per-CU blocks, i.e. 2-3 tiles per block behind a 13 us fixed part (prologue + the eight-wave reduce tree);
 // here the same block budget covers all the convs, every block walks 10+ tiles, and the fixed part is paid once per block instead
 // of once per conv and block: 234 blocks x 68 us for a dense block at 16 x 40 x 40 against 5 x (160 blocks x 22-27 us).
-template <bool VEC>
+template <bool VEC, int DB>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_batch_kernel(const WgradBatchArgs b) {
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;      // block-uniform
@@ -462,7 +693,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_f16x3_batch_kernel(const Wg
   const int nicb = b.nicb[j], nocb = b.nocb[j];
   const int bz = r % nocb; r /= nocb;
   const int by = r % nicb; r /= nicb;
-  wgrad_f16x3_body<9, VEC>(b.a[j], r, by, bz, nicb, nocb);
+  wgrad_f16x3_body<9, VEC, DB>(b.a[j], r, by, bz, nicb, nocb);
 }
 
 // dW[oc][ic][tap] += sum over the nx blocks of part[bx][icb][ocb][tap][m][n]
@@ -615,6 +846,21 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   return (size_t)nblk_x * pairs * a0.taps * 1024;
 }
 
+// LDS form of the f16x3 weight-gradient kernels: 2 = double-buffered, interleaved (the default of the 3x3 kernels: same box,
+// profiles/r05_ab_wgrad_lds_forms.txt: batched launch 260.8 -> 246.4 us, one-conv launch 57.7 -> 52.6 us), 1 = double-buffered
+// with one block store per tile (HCF_WG_DB_BLOCK=1), 0 = single buffer (HCF_WG_SINGLE_BUF=1; the default of the 1x1 kernels: two
+// tap positions per tile leave nothing to hide the slots under, 24.4 against 26.1 us; HCF_WG_INTERLEAVE_ALL=1 gives them form 2).
+// Read per launch: the tests compare the forms inside one process. All three are bit-identical.
+static int wgrad_lds_form(int taps) {
+  const char* const e = getenv("HCF_WG_SINGLE_BUF");
+  if (e && atoi(e) != 0) return 0;
+  const char* const b = getenv("HCF_WG_DB_BLOCK");
+  if (b && atoi(b) != 0) return 1;
+  if (taps == 9) return 2;
+  const char* const i = getenv("HCF_WG_INTERLEAVE_ALL");
+  return (i && atoi(i) != 0) ? 2 : 0;
+}
+
 int launch_wgrad_reduce_batch(const WgradReduceJob* jobs_dev, int njobs, long long nblocks, hipStream_t st) {
   if (!jobs_dev || njobs < 1 || nblocks < 1 || nblocks > 0x7fffffffLL) return HCF_ERR_ARG;
   hipLaunchKernelGGL(wgrad::wgrad_reduce_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, njobs);
@@ -646,10 +892,11 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer
     vec = vec && (((a.src[i].cs | a.src[i].c0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src[i].p) & 15) == 0);
   if (a.g_max) {
     // f16 matrix cores (one-time opt-in to > 64 KB of dynamic LDS per instantiation)
-    static bool attr_dev[64][4] = {};     // per device: several GPUs in one process (nn.DataParallel replicas)
+    static bool attr_dev[64][12] = {};    // per device: several GPUs in one process (nn.DataParallel replicas)
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
-    bool (&attr)[4] = attr_dev[dev_];
+    bool (&attr)[12] = attr_dev[dev_];
+    const int db = wgrad_lds_form(a.taps);
     auto go = [&](auto fn, int idx, int ldsb) {
       if (!attr[idx]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return false;
@@ -659,10 +906,21 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer
       return true;
     };
     bool ok;
-    if (a.taps == 9 && vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, true>, 0, wgrad::Wg16<9>::LDS_BYTES);
-    else if (a.taps == 9) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, false>, 1, wgrad::Wg16<9>::LDS_BYTES);
-    else if (vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<1, true>, 2, wgrad::Wg16<1>::LDS_BYTES);
-    else ok = go(wgrad::conv_wgrad_f16x3_kernel<1, false>, 3, wgrad::Wg16<1>::LDS_BYTES);
+    if (db == 2) {
+      if (a.taps == 9 && vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, true, 2>, 8, wgrad::Wg16<9>::LDS2_BYTES);
+      else if (a.taps == 9) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, false, 2>, 9, wgrad::Wg16<9>::LDS2_BYTES);
+      else if (vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<1, true, 2>, 10, wgrad::Wg16<1>::LDS2_BYTES);
+      else ok = go(wgrad::conv_wgrad_f16x3_kernel<1, false, 2>, 11, wgrad::Wg16<1>::LDS2_BYTES);
+    } else if (db == 1) {
+      if (a.taps == 9 && vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, true, 1>, 4, wgrad::Wg16<9>::LDS2_BYTES);
+      else if (a.taps == 9) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, false, 1>, 5, wgrad::Wg16<9>::LDS2_BYTES);
+      else if (vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<1, true, 1>, 6, wgrad::Wg16<1>::LDS2_BYTES);
+      else ok = go(wgrad::conv_wgrad_f16x3_kernel<1, false, 1>, 7, wgrad::Wg16<1>::LDS2_BYTES);
+    } else
+    if (a.taps == 9 && vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, true, 0>, 0, wgrad::Wg16<9>::LDS_BYTES);
+    else if (a.taps == 9) ok = go(wgrad::conv_wgrad_f16x3_kernel<9, false, 0>, 1, wgrad::Wg16<9>::LDS_BYTES);
+    else if (vec) ok = go(wgrad::conv_wgrad_f16x3_kernel<1, true, 0>, 2, wgrad::Wg16<1>::LDS_BYTES);
+    else ok = go(wgrad::conv_wgrad_f16x3_kernel<1, false, 0>, 3, wgrad::Wg16<1>::LDS_BYTES);
     if (!ok) return HCF_ERR_HIP;
   } else
   if (a.taps == 9 && vec) hipLaunchKernelGGL((wgrad::conv_wgrad_kernel<9, true>), grid, dim3(256), 0, st, a);
@@ -715,16 +973,19 @@ int launch_conv_wgrad_batch(const WgradArgs* jobs, int n, hipStream_t st, WgradR
     defer[i].a = a; defer[i].nx = nblk_x; defer[i].nicb = nicb; defer[i].nocb = nocb; defer[i].nbx = (9 * 1024 + 255) / 256; defer[i].blk0 = 0;
   }
   b.blk0[n] = total;
-  static bool attr_dev[64] = {};
+  static bool attr_dev[64][3] = {};
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
-  auto fn = wgrad::conv_wgrad_f16x3_batch_kernel<true>;
-  if (!attr_dev[dev_]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, wgrad::Wg16<9>::LDS_BYTES) != hipSuccess)
+  const int db = wgrad_lds_form(9);
+  auto fn = db == 2 ? wgrad::conv_wgrad_f16x3_batch_kernel<true, 2>
+          : db == 1 ? wgrad::conv_wgrad_f16x3_batch_kernel<true, 1> : wgrad::conv_wgrad_f16x3_batch_kernel<true, 0>;
+  const int ldsb = db ? wgrad::Wg16<9>::LDS2_BYTES : wgrad::Wg16<9>::LDS_BYTES;
+  if (!attr_dev[dev_][db]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess)
       return HCF_ERR_HIP;
-    attr_dev[dev_] = true;
+    attr_dev[dev_][db] = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(512), wgrad::Wg16<9>::LDS_BYTES, st, b);
+  hipLaunchKernelGGL(fn, dim3((unsigned)total), dim3(512), ldsb, st, b);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 

@@ -117,6 +117,46 @@ def test_conv2d_weight_gradient_f16x3_ranges(gscale):
     assert float(err.max()) <= 5e-6, float(err.max())
 
 
+@pytest.mark.parametrize("shape", [(16, 40, 40, [64, 32], 32, 3), (3, 40, 72, [64, 32], 64, 3), (2, 80, 96, [32], 32, 3),
+                                   (4, 64, 64, [64, 64, 64], 64, 3), (8, 64, 96, [64, 64, 64], 64, 3), (1, 8, 32, [32], 32, 3),
+                                   (5, 20, 20, [21], 12, 3), (4, 48, 64, [64], 64, 1), (6, 64, 96, [64, 64, 64], 64, 1),
+                                   (3, 9, 33, [48], 24, 1)])
+def test_conv2d_weight_gradient_f16x3_lds_forms_are_bit_identical(shape, monkeypatch):
+    """The f16x3 weight-gradient kernels stage their tiles through two LDS buffers, one staging slot converted, written and
+    reloaded per tap in the shadow of that tap's MFMAs (the default); HCF_WG_DB_BLOCK=1 writes a tile's slots in one block,
+    HCF_WG_SINGLE_BUF=1 is the single-buffer form (barrier, convert + write, barrier, MFMAs). All three run the same MFMAs
+    on the same fragments in the same order: the results are bit-identical (one, two, four and ten tiles per block, ragged
+    tiles, channel tails, strips, 1x1), and right against fp64."""
+    from hcflow_amd import ops
+    B, H, W, cs, cout, k = shape
+    g = _gen(31 * B + W + k)
+    srcs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    gy = torch.randn(B, cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(torch.cat(srcs, 1).double(), (cout, sum(cs), k, k), gy.double(), stride=1, padding=k // 2)
+    w0 = torch.zeros(cout, sum(cs), k, k)
+    ops.set_precision("f16x3")
+    try:
+        res = {}
+        for form in ("interleaved", "block", "single"):
+            monkeypatch.delenv("HCF_WG_DB_BLOCK", raising=False)
+            monkeypatch.delenv("HCF_WG_SINGLE_BUF", raising=False)
+            monkeypatch.setenv("HCF_WG_INTERLEAVE_ALL", "1")       # (1x1 kernels default to the single-buffer form)
+            if form == "block":
+                monkeypatch.setenv("HCF_WG_DB_BLOCK", "1")
+            if form == "single":
+                monkeypatch.setenv("HCF_WG_SINGLE_BUF", "1")
+            for _ in range(2):
+                _, dw, _ = ops.conv2d_backward([t.cuda() for t in srcs], w0, gy.cuda(), need_input_grads=False)
+                res.setdefault(form, []).append(dw.cpu())
+    finally:
+        ops.set_precision("exact")
+    for form in res:
+        assert torch.equal(res[form][0], res[form][1]), form       # reproducible (no race between the two LDS buffers)
+    assert torch.equal(res["interleaved"][0], res["single"][0])
+    assert torch.equal(res["block"][0], res["single"][0])
+    assert _rel(res["interleaved"][0], ref) <= 3e-6
+
+
 GRADS = ["grad_sr4_tiny", "grad_sr8_tiny"]
 
 
@@ -148,6 +188,37 @@ def test_nll_step_gradients_match_reference(name, precision):
     assert all(np.isfinite(x).all() for x in grads)
     assert net.engine().fallback_count() == 0
     check_grads_against_fixture(g, grads)
+
+
+def test_nll_step_gradients_are_bit_identical_across_the_weight_gradient_lds_forms(monkeypatch):
+    """The engine's batched weight-gradient launch (the five convs of a dense block in one grid) and its one-conv launches under
+    the three LDS forms of the f16x3 kernel: every parameter gradient of one NLL step is bit-identical."""
+    from tests.util import load_golden, params_for, t
+    from hcflow_amd import HCFlowNet_SR
+    g = load_golden("grad_sr4_tiny")
+    cfg, p = params_for(g)
+    got = {}
+    for form in ("interleaved", "block", "single"):
+        monkeypatch.delenv("HCF_WG_DB_BLOCK", raising=False)
+        monkeypatch.delenv("HCF_WG_SINGLE_BUF", raising=False)
+        if form == "block":
+            monkeypatch.setenv("HCF_WG_DB_BLOCK", "1")
+        if form == "single":
+            monkeypatch.setenv("HCF_WG_SINGLE_BUF", "1")
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(p, strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to("cuda:0").train().set_precision("f16x3")
+        _, nll = net(hr=t(g["hr"]).cuda(), lr=t(g["lr"]).cuda(), reverse=False, noise=t(g["fwd_noise"]).cuda())
+        nll.backward()
+        torch.cuda.synchronize()
+        got[form] = {k: v.grad.cpu().clone() for k, v in net.named_parameters() if v.grad is not None}
+    assert len(got["single"]) > 50
+    for k, v in got["single"].items():
+        assert torch.equal(got["interleaved"][k], v), k
+        assert torch.equal(got["block"][k], v), k
 
 
 def _fresh_sr(name, seed, inited=True):
