@@ -192,6 +192,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16* lds_v4i16;
 
 // eight consecutive K (pixel) values of this lane's channel: pixels +0..3 and +4..7 (4 x 64 B further)
@@ -383,7 +384,17 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
     // instructions) issues in the shadow of that tap's three MFMAs (96 matrix-pipe cycles), one barrier per tile. The
     // single-buffer form runs barrier, convert + write (all 16 waves of the CU at once, matrix pipe idle), barrier, MFMAs.
     constexpr int BUFB = C::BUF_BYTES;
-    constexpr int NS = NX + NG, SPP = (NS + 2 * TAPS - 1) / (2 * TAPS);      // staging slots, slots per (step, tap) position
+    // staging slots of this form: FOUR threads per pixel, 8 channels (two 16-byte loads behind ONE address computation, one
+    // ds_write_b128 per plane) -- half the slots, i.e. half the per-slot address / mask arithmetic of the 8-threads-per-pixel
+    // mapping of the other forms; the same registers (rx[2 s], rx[2 s + 1]), the same values at the same LDS addresses
+    constexpr int NX2 = (HP * 4 + 511) / 512, NG2 = (TH * TW * 4) / 512;
+    static_assert(2 * NX2 <= NX && 2 * NG2 <= NG, "the slot pairs fit the staging registers");
+    constexpr int NS = NX2 + NG2, SPP = (NS + 2 * TAPS - 1) / (2 * TAPS);    // staging slots, slots per (step, tap) position
+    const int c8t = (tid & 3) * 8;
+    const int vxa = max(0, min(4, icn - c8t)), vxb = max(0, min(4, icn - c8t - 4));
+    const int vga = max(0, min(4, ocn - c8t)), vgb = max(0, min(4, ocn - c8t - 4));
+    const int c8xa = min(c8t, max(0, (icn - 1) & ~3)), c8xb = min(c8t + 4, max(0, (icn - 1) & ~3));
+    const int c8ga = min(c8t, max(0, (ocn - 1) & ~3)), c8gb = min(c8t + 4, max(0, (ocn - 1) & ~3));
     int x0n = 0, y0n = 0, btn = 0;                     // tile whose loads are being issued
 #define HCF_WG_COORDS(TILE)                                                                                   \
     {                                                                                                         \
@@ -391,81 +402,94 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
       btn = sw ? 0 : (TILE) / (tiles_x * tiles_y);                                                            \
       x0n = txb_ * TW; y0n = tyb_ * TH;                                                                       \
     }
-#define HCF_WG_LOAD_SLOT(SL)                                                                                  \
-    if ((SL) < NX) {                                                                                          \
-      const int s_ = (SL);                                                                                    \
-      const int hp = min((tidl_ + 512 * s_) >> 3, HP - 1);                                                      \
-      const int hy = hp / HW, hxx_ = hp - hy * HW;                                                            \
-      const int y = y0n + hy - PAD;                                                                           \
-      int x = x0n + hxx_ - PAD, b_ = btn;                                                                     \
+#define HCF_WG_LOAD_SLOT(SL)                                                                                          \
+    if ((SL) < NX2) {                                                                                                 \
+      const int s_ = (SL);                                                                                            \
+      const int hp = min((tidl_ + 512 * s_) >> 2, HP - 1);                                                            \
+      const int hy = hp / HW, hxx_ = hp - hy * HW;                                                                    \
+      const int y = y0n + hy - PAD;                                                                                   \
+      int x = x0n + hxx_ - PAD, b_ = btn;                                                                             \
       /* strips: virtual column -> (image, column), branch-free (sw is block-uniform: selects, no basic-block split) */ \
-      const int vc_ = min(max(x, 0), svw - 1);                                                                \
-      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                   \
-      const int xr_ = vc_ - bq_ * sw;                                                                         \
-      const bool okx_ = sw ? (x >= 0 && x < svw && xr_ < W) : (x >= 0 && x < W);                              \
-      b_ = sw ? bq_ : b_;                                                                                     \
-      x = sw ? xr_ : x;                                                                                       \
-      mskx = (mskx & ~(1u << s_)) | ((y >= 0 && y < H && okx_) ? (1u << s_) : 0u);                            \
-      const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                           \
-      const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                            \
-      f32x4 v;                                                                                                \
-      if (VEC) {                                                                                              \
-        v = *reinterpret_cast<const f32x4*>(p + c4x);                                                         \
-      } else {                                                                                                \
-        v.x = p[min(c4t, icn - 1)]; v.y = p[min(c4t + 1, icn - 1)];                                           \
-        v.z = p[min(c4t + 2, icn - 1)]; v.w = p[min(c4t + 3, icn - 1)];                                       \
-      }                                                                                                       \
-      rx[s_] = v;                                                                                             \
-    } else if ((SL) < NS) {                                                                                   \
-      const int s_ = (SL) - NX;                                                                               \
-      const int px = (tidl_ + 512 * s_) >> 3;                                                                   \
-      const int y = y0n + (px >> 5);                                                                          \
-      int x = x0n + (px & 31), b_ = btn;                                                                      \
-      const int vc_ = min(x, svw - 1);                                                                        \
-      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                   \
-      const int xr_ = vc_ - bq_ * sw;                                                                         \
-      const bool okx_ = sw ? (x < svw && xr_ < W) : (x < W);                                                  \
-      b_ = sw ? bq_ : b_;                                                                                     \
-      x = sw ? xr_ : x;                                                                                       \
-      mskg = (mskg & ~(1u << s_)) | ((y < H && okx_) ? (1u << s_) : 0u);                                      \
-      const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;       \
-      f32x4 v;                                                                                                \
-      if (VEC) {                                                                                              \
-        v = *reinterpret_cast<const f32x4*>(p + c4g);                                                         \
-      } else {                                                                                                \
-        v.x = p[min(c4t, ocn - 1)]; v.y = p[min(c4t + 1, ocn - 1)];                                           \
-        v.z = p[min(c4t + 2, ocn - 1)]; v.w = p[min(c4t + 3, ocn - 1)];                                       \
-      }                                                                                                       \
-      rg[s_] = v;                                                                                             \
+      const int vc_ = min(max(x, 0), svw - 1);                                                                        \
+      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                           \
+      const int xr_ = vc_ - bq_ * sw;                                                                                 \
+      const bool okx_ = sw ? (x >= 0 && x < svw && xr_ < W) : (x >= 0 && x < W);                                      \
+      b_ = sw ? bq_ : b_;                                                                                             \
+      x = sw ? xr_ : x;                                                                                               \
+      mskx = (mskx & ~(1u << s_)) | ((y >= 0 && y < H && okx_) ? (1u << s_) : 0u);                                    \
+      const int yc = min(max(y, 0), H - 1) >> up, xc = min(max(x, 0), W - 1) >> up;                                   \
+      const float* p = xbase + ((size_t)((size_t)b_ * Hs + yc) * Ws + xc) * sv.cs;                                    \
+      f32x4 va, vb;                                                                                                   \
+      if (VEC) {                                                                                                      \
+        va = *reinterpret_cast<const f32x4*>(p + c8xa);                                                               \
+        vb = *reinterpret_cast<const f32x4*>(p + c8xb);                                                               \
+      } else {                                                                                                        \
+        va.x = p[min(c8t, icn - 1)]; va.y = p[min(c8t + 1, icn - 1)];                                                 \
+        va.z = p[min(c8t + 2, icn - 1)]; va.w = p[min(c8t + 3, icn - 1)];                                             \
+        vb.x = p[min(c8t + 4, icn - 1)]; vb.y = p[min(c8t + 5, icn - 1)];                                             \
+        vb.z = p[min(c8t + 6, icn - 1)]; vb.w = p[min(c8t + 7, icn - 1)];                                             \
+      }                                                                                                               \
+      rx[2 * s_] = va;                                                                                                \
+      rx[2 * s_ + 1] = vb;                                                                                            \
+    } else if ((SL) < NS) {                                                                                           \
+      const int s_ = (SL) - NX2;                                                                                      \
+      const int px = (tidl_ + 512 * s_) >> 2;                                                                         \
+      const int y = y0n + (px >> 5);                                                                                  \
+      int x = x0n + (px & 31), b_ = btn;                                                                              \
+      const int vc_ = min(x, svw - 1);                                                                                \
+      const int bq_ = (int)__umulhi((unsigned)vc_, smagic);                                                           \
+      const int xr_ = vc_ - bq_ * sw;                                                                                 \
+      const bool okx_ = sw ? (x < svw && xr_ < W) : (x < W);                                                          \
+      b_ = sw ? bq_ : b_;                                                                                             \
+      x = sw ? xr_ : x;                                                                                               \
+      mskg = (mskg & ~(1u << s_)) | ((y < H && okx_) ? (1u << s_) : 0u);                                              \
+      const float* p = gbase + ((size_t)((size_t)b_ * H + min(y, H - 1)) * W + min(x, W - 1)) * a.g.cs;               \
+      f32x4 va, vb;                                                                                                   \
+      if (VEC) {                                                                                                      \
+        va = *reinterpret_cast<const f32x4*>(p + c8ga);                                                               \
+        vb = *reinterpret_cast<const f32x4*>(p + c8gb);                                                               \
+      } else {                                                                                                        \
+        va.x = p[min(c8t, ocn - 1)]; va.y = p[min(c8t + 1, ocn - 1)];                                                 \
+        va.z = p[min(c8t + 2, ocn - 1)]; va.w = p[min(c8t + 3, ocn - 1)];                                             \
+        vb.x = p[min(c8t + 4, ocn - 1)]; vb.y = p[min(c8t + 5, ocn - 1)];                                             \
+        vb.z = p[min(c8t + 6, ocn - 1)]; vb.w = p[min(c8t + 7, ocn - 1)];                                             \
+      }                                                                                                               \
+      rg[2 * s_] = va;                                                                                                \
+      rg[2 * s_ + 1] = vb;                                                                                            \
     }
-#define HCF_WG_STORE_SLOT(SL, BUF)                                                                            \
-    if ((SL) < NX) {                                                                                          \
-      const int s_ = (SL);                                                                                    \
-      char* const xb_ = lds + (BUF) * BUFB;                                                                   \
-      const int q = tidl_ + 512 * s_;                                                                           \
-      f32x4 v = rx[s_];                                                                                       \
-      const bool ok = (mskx >> s_) & 1u;                                                                      \
-      v.x = (ok && vx > 0) ? v.x : 0.f; v.y = (ok && vx > 1) ? v.y : 0.f;                                     \
-      v.z = (ok && vx > 2) ? v.z : 0.f; v.w = (ok && vx > 3) ? v.w : 0.f;                                     \
-      u32x2 h, l;                                                                                             \
-      split_hl_x(v, h, l);                                                                                    \
+#define HCF_WG_STORE_SLOT(SL, BUF)                                                                                    \
+    if ((SL) < NX2) {                                                                                                 \
+      const int s_ = (SL);                                                                                            \
+      char* const xb_ = lds + (BUF) * BUFB;                                                                           \
+      f32x4 va = rx[2 * s_], vb = rx[2 * s_ + 1];                                                                     \
+      const bool ok = (mskx >> s_) & 1u;                                                                              \
+      va.x = (ok && vxa > 0) ? va.x : 0.f; va.y = (ok && vxa > 1) ? va.y : 0.f;                                       \
+      va.z = (ok && vxa > 2) ? va.z : 0.f; va.w = (ok && vxa > 3) ? va.w : 0.f;                                       \
+      vb.x = (ok && vxb > 0) ? vb.x : 0.f; vb.y = (ok && vxb > 1) ? vb.y : 0.f;                                       \
+      vb.z = (ok && vxb > 2) ? vb.z : 0.f; vb.w = (ok && vxb > 3) ? vb.w : 0.f;                                       \
+      u32x2 ha, la, hb, lb;                                                                                           \
+      split_hl_x(va, ha, la);                                                                                         \
+      split_hl_x(vb, hb, lb);                                                                                         \
       /* threads past the halo's last pixel hold pixel HP - 1's data (their load was clamped to it): they write the same values */ \
-      /* to the same address as its owner instead of branching around the store */                            \
-      const int qp_ = min(q >> 3, HP - 1);                                                                    \
-      *reinterpret_cast<u32x2*>(xb_ + qp_ * 64 + c4t * 2) = h;                                                \
-      *reinterpret_cast<u32x2*>(xb_ + XB + qp_ * 64 + c4t * 2) = l;                                           \
-    } else if ((SL) < NS) {                                                                                   \
-      const int s_ = (SL) - NX;                                                                               \
-      char* const gb_ = lds + (BUF) * BUFB + 2 * XB;                                                          \
-      const int q = tidl_ + 512 * s_;                                                                           \
-      f32x4 v = rg[s_] * g_s;                                                                                 \
-      const bool ok = (mskg >> s_) & 1u;                                                                      \
-      v.x = (ok && vg > 0) ? v.x : 0.f; v.y = (ok && vg > 1) ? v.y : 0.f;                                     \
-      v.z = (ok && vg > 2) ? v.z : 0.f; v.w = (ok && vg > 3) ? v.w : 0.f;                                     \
-      u32x2 h, l;                                                                                             \
-      split_hl_g2(v, h, l);                                                                                   \
-      *reinterpret_cast<u32x2*>(gb_ + (q >> 3) * 64 + c4t * 2) = h;                                           \
-      *reinterpret_cast<u32x2*>(gb_ + GB + (q >> 3) * 64 + c4t * 2) = l;                                      \
+      /* to the same address as its owner instead of branching around the store */                                    \
+      const int qp_ = min((tidl_ + 512 * s_) >> 2, HP - 1);                                                           \
+      *reinterpret_cast<u32x4*>(xb_ + qp_ * 64 + c8t * 2) = u32x4{ha.x, ha.y, hb.x, hb.y};                            \
+      *reinterpret_cast<u32x4*>(xb_ + XB + qp_ * 64 + c8t * 2) = u32x4{la.x, la.y, lb.x, lb.y};                       \
+    } else if ((SL) < NS) {                                                                                           \
+      const int s_ = (SL) - NX2;                                                                                      \
+      char* const gb_ = lds + (BUF) * BUFB + 2 * XB;                                                                  \
+      f32x4 va = rg[2 * s_] * g_s, vb = rg[2 * s_ + 1] * g_s;                                                         \
+      const bool ok = (mskg >> s_) & 1u;                                                                              \
+      va.x = (ok && vga > 0) ? va.x : 0.f; va.y = (ok && vga > 1) ? va.y : 0.f;                                       \
+      va.z = (ok && vga > 2) ? va.z : 0.f; va.w = (ok && vga > 3) ? va.w : 0.f;                                       \
+      vb.x = (ok && vgb > 0) ? vb.x : 0.f; vb.y = (ok && vgb > 1) ? vb.y : 0.f;                                       \
+      vb.z = (ok && vgb > 2) ? vb.z : 0.f; vb.w = (ok && vgb > 3) ? vb.w : 0.f;                                       \
+      u32x2 ha, la, hb, lb;                                                                                           \
+      split_hl_g2(va, ha, la);                                                                                        \
+      split_hl_g2(vb, hb, lb);                                                                                        \
+      const int qp_ = (tidl_ + 512 * s_) >> 2;                                                                        \
+      *reinterpret_cast<u32x4*>(gb_ + qp_ * 64 + c8t * 2) = u32x4{ha.x, ha.y, hb.x, hb.y};                            \
+      *reinterpret_cast<u32x4*>(gb_ + GB + qp_ * 64 + c8t * 2) = u32x4{la.x, la.y, lb.x, lb.y};                       \
     }
     // one tile: ST = tile + 1 exists (its registers go to the other buffer), LD = tile + 2 exists (its loads are issued)
 #define HCF_WG_TILE_BODY(ST, LD)                                                                              \
