@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 // channel c, i.e. exactly four consecutive K values of an MFMA operand row; two reads give the eight a lane needs. A tap
 // only moves the pixel index, so all 9 taps read the same halo image at different (immediate) offsets, and 32 lanes of one
 // read cover 256 contiguous bytes (conflict-free).
-// Block = 8 waves (one image row of the 8 x 32 tile each, all 9 taps: 144 accumulator registers), one block per CU slot of
-// 76 KB LDS; the eight per-wave partial tiles are added in a fixed tree through LDS, then the same scratch / reduce path.
+// Block = 8 waves (one image row of the 8 x 32 tile each, all 9 taps: 144 accumulator registers), one block per CU: two 76 KB
+// LDS buffers in the default form (Wg16::LDS2_BYTES), one 92 KB buffer in the single-buffer form; the eight per-wave partial tiles are added in a fixed tree through LDS, then the same scratch / reduce path.
 typedef short v4i16 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -379,10 +379,11 @@ __device__ __forceinline__ void wgrad_f16x3_body(const WgradArgs& a, const int b
   const int t0 = bxi * a.tpb, t1 = min(ntiles, t0 + a.tpb);
   if constexpr (DB == 2) {
     // ---- double-buffered, interleaved form (the default): tile i's MFMAs read LDS buffer i & 1 while the staging registers of
-    // tile i + 1 (loaded a whole tile earlier) are converted and written to the OTHER buffer ONE SLOT PER TAP, each slot's
-    // register then reloaded with tile i + 2: the convert / ds_write / address / global_load stream of a slot (~40 VALU
-    // instructions) issues in the shadow of that tap's three MFMAs (96 matrix-pipe cycles), one barrier per tile. The
-    // single-buffer form runs barrier, convert + write (all 16 waves of the CU at once, matrix pipe idle), barrier, MFMAs.
+    // tile i + 1 (loaded a whole tile earlier) are converted and written to the OTHER buffer ONE SLOT PER TAP (the five slots of
+    // a 3x3 tile ride on the first five taps), each slot's registers then reloaded with tile i + 2: the convert / ds_write /
+    // address / global_load stream of a slot (~70 VALU instructions) issues in the shadow of the taps' MFMAs (96 matrix-pipe
+    // cycles per tap and wave), one barrier per tile. The single-buffer form runs barrier, convert + write (all 16 waves of the
+    // CU at once, matrix pipe idle), barrier, MFMAs. Same MFMAs, same fragments, same order: bit-identical results.
     constexpr int BUFB = C::BUF_BYTES;
     // staging slots of this form: FOUR threads per pixel, 8 channels (two 16-byte loads behind ONE address computation, one
     // ds_write_b128 per plane) -- half the slots, i.e. half the per-slot address / mask arithmetic of the 8-threads-per-pixel
