@@ -871,19 +871,15 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a0, int* out_nblk_x, int* out_
   return (size_t)nblk_x * pairs * a0.taps * 1024;
 }
 
-// LDS form of the f16x3 weight-gradient kernels: 2 = double-buffered, interleaved (the default of the 3x3 kernels: same box,
-// profiles/r05_ab_wgrad_lds_forms.txt: batched launch 260.8 -> 246.4 us, one-conv launch 57.7 -> 52.6 us), 1 = double-buffered
-// with one block store per tile (HCF_WG_DB_BLOCK=1), 0 = single buffer (HCF_WG_SINGLE_BUF=1; the default of the 1x1 kernels: two
-// tap positions per tile leave nothing to hide the slots under, 24.4 against 26.1 us; HCF_WG_INTERLEAVE_ALL=1 gives them form 2).
+// LDS form of the f16x3 weight-gradient kernels: 2 = double-buffered, interleaved, four threads per pixel (the default; same box,
+// profiles/r05_ab_wgrad_lds_forms.txt: batched launch 263.4 -> 229.2 us, one-conv 3x3 launch 56.3 -> 49.1 us, 1x1 launch
+// 25.3 -> 21.0 us), 1 = double-buffered with one block store per tile (HCF_WG_DB_BLOCK=1), 0 = single buffer (HCF_WG_SINGLE_BUF=1).
 // Read per launch: the tests compare the forms inside one process. All three are bit-identical.
-static int wgrad_lds_form(int taps) {
+static int wgrad_lds_form() {
   const char* const e = getenv("HCF_WG_SINGLE_BUF");
   if (e && atoi(e) != 0) return 0;
   const char* const b = getenv("HCF_WG_DB_BLOCK");
-  if (b && atoi(b) != 0) return 1;
-  if (taps == 9) return 2;
-  const char* const i = getenv("HCF_WG_INTERLEAVE_ALL");
-  return (i && atoi(i) != 0) ? 2 : 0;
+  return (b && atoi(b) != 0) ? 1 : 2;
 }
 
 int launch_wgrad_reduce_batch(const WgradReduceJob* jobs_dev, int njobs, long long nblocks, hipStream_t st) {
@@ -921,7 +917,7 @@ int launch_conv_wgrad(const WgradArgs& a0, hipStream_t st, WgradReduceJob* defer
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
     bool (&attr)[12] = attr_dev[dev_];
-    const int db = wgrad_lds_form(a.taps);
+    const int db = wgrad_lds_form();
     auto go = [&](auto fn, int idx, int ldsb) {
       if (!attr[idx]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return false;
@@ -1001,7 +997,7 @@ int launch_conv_wgrad_batch(const WgradArgs* jobs, int n, hipStream_t st, WgradR
   static bool attr_dev[64][3] = {};
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return HCF_ERR_HIP;
-  const int db = wgrad_lds_form(9);
+  const int db = wgrad_lds_form();
   auto fn = db == 2 ? wgrad::conv_wgrad_f16x3_batch_kernel<true, 2>
           : db == 1 ? wgrad::conv_wgrad_f16x3_batch_kernel<true, 1> : wgrad::conv_wgrad_f16x3_batch_kernel<true, 0>;
   const int ldsb = db ? wgrad::Wg16<9>::LDS2_BYTES : wgrad::Wg16<9>::LDS_BYTES;

@@ -140,7 +140,6 @@ def test_conv2d_weight_gradient_f16x3_lds_forms_are_bit_identical(shape, monkeyp
         for form in ("interleaved", "block", "single"):
             monkeypatch.delenv("HCF_WG_DB_BLOCK", raising=False)
             monkeypatch.delenv("HCF_WG_SINGLE_BUF", raising=False)
-            monkeypatch.setenv("HCF_WG_INTERLEAVE_ALL", "1")       # (1x1 kernels default to the single-buffer form)
             if form == "block":
                 monkeypatch.setenv("HCF_WG_DB_BLOCK", "1")
             if form == "single":
