@@ -12,6 +12,7 @@
 #include "hcf_conv_wino_v5.h"      // version 5: the ping-pong experiment (tools/micro only)
 #include "hcf_conv_wino_v6.h"      // version 6 / 7: the row phase pipelined under the position loop (round 5; tools/micro only)
 #include "hcf_conv_wino1d.h"       // version 8 / 9: the 1-D form, F(2,3) along x and direct along y (round 5; tools/micro only)
+#include "hcf_conv_wino6.h"        // version 10: F(4x4, 3x3), 64 output channels (round 6)
 
 using namespace hcf::wino;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -134,7 +135,7 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> pk;
     const int ver = ((version >= 4) && P.cout != 64) ? 2 : version;         // v4 / v5 / v6 (6, 7) are the 64-output-channel kernels         // v4 / v5 are the 64-output-channel kernels
     if (ver >= 8 && P.fuse) { printf("%-34s (no fused 1x1 form in v8)\n", P.name); continue; }
-    if (!((ver >= 8) ? pack_weights_wino1d(w.data(), cin, P.cout, pk) : (ver >= 4) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
+    if (!((ver == 10) ? hcf::wino6::pack_weights_wino6(w.data(), cin, P.cout, pk) : (ver >= 8) ? pack_weights_wino1d(w.data(), cin, P.cout, pk) : (ver >= 4) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
@@ -161,7 +162,7 @@ int main(int argc, char** argv) {
       a.f_w = dfw; a.f_bias = dbias2; a.f_scale = dscale2; a.f_act = 1;
     }
     unsigned long long* dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128)); a.dbg = dbg;
-    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -186,9 +187,9 @@ int main(int argc, char** argv) {
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;
