@@ -8,11 +8,9 @@
 #include <cmath>
 #include <vector>
 #include "hcf_conv_wino.h"
-#include "hcf_conv_wino_v1.h"      // version 1 of the series (tools/micro only)
-#include "hcf_conv_wino_v5.h"      // version 5: the ping-pong experiment (tools/micro only)
-#include "hcf_conv_wino_v6.h"      // version 6 / 7: the row phase pipelined under the position loop (round 5; tools/micro only)
-#include "hcf_conv_wino1d.h"       // version 8 / 9: the 1-D form, F(2,3) along x and direct along y (round 5; tools/micro only)
-#include "hcf_conv_wino6.h"        // version 10: F(4x4, 3x3), 64 output channels (round 6)
+#include "hcf_conv_wino6.h"        // version 10: F(4x4, 3x3), 64 output channels (round 6; tools/micro only, profiles/r06_notes.md)
+// (versions 1, 5, 6 / 7, 8 / 9 of the series -- first kernel, ping-pong, pipelined row phase, 1-D form -- were removed in round 6:
+//  their measurements are in profiles/r03..r05_notes.md, the sources in the history before this commit)
 
 using namespace hcf::wino;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -113,6 +111,12 @@ int main(int argc, char** argv) {
       {"conv5 192->64 @256 B=4 (336 MB)", 4, 256, 256, 64, 128, 64, 0, true},
       {"conv5 192->64 @256 B=6 (503 MB)", 6, 256, 256, 64, 128, 64, 0, true},
       {"conv5 192->64 @256 B=8 (671 MB)", 8, 256, 256, 64, 128, 64, 0, true},
+      // round 6 (F(4x4,3x3), version 10): several samples and units per block with residual / activation / ragged edges
+      {"check 64+128->64 res lrelu B=2", 2, 21, 37, 64, 128, 64, 2, true},
+      {"check 16+64->64 relu B=3", 3, 16, 33, 16, 64, 64, 1, false},
+      {"check 64->64 res B=5 exact", 5, 32, 32, 64, 0, 64, 0, true},
+      {"check 64+64->64 B=1 H=7", 1, 7, 100, 64, 64, 64, 2, false},
+      {"check 64->64 plain B=2", 2, 16, 32, 64, 0, 64, 0, false},
   };
   const int nprob = sizeof(probs) / sizeof(probs[0]);
   for (int pi = 0; pi < nprob; ++pi) {
@@ -133,9 +137,9 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < w.size(); ++i) w[i] = hashf(i, 3) * 0.5f / sqrtf((float)cin * 9.f);
     for (int i = 0; i < P.cout; ++i) { bias[i] = hashf(i, 5) * 0.1f; scale[i] = 1.f + 0.1f * hashf(i, 6); }
     std::vector<uint16_t> pk;
-    const int ver = ((version >= 4) && P.cout != 64) ? 2 : version;         // v4 / v5 / v6 (6, 7) are the 64-output-channel kernels         // v4 / v5 are the 64-output-channel kernels
-    if (ver >= 8 && P.fuse) { printf("%-34s (no fused 1x1 form in v8)\n", P.name); continue; }
-    if (!((ver == 10) ? hcf::wino6::pack_weights_wino6(w.data(), cin, P.cout, pk) : (ver >= 8) ? pack_weights_wino1d(w.data(), cin, P.cout, pk) : (ver >= 4) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
+    const int ver = ((version >= 4) && P.cout != 64) ? 2 : version;         // version 4 / 10 are 64-output-channel kernels
+    if (ver == 10 && P.fuse) { printf("%-34s (no fused 1x1 form in version 10)\n", P.name); continue; }
+    if (!((ver == 10) ? hcf::wino6::pack_weights_wino6(w.data(), cin, P.cout, pk) : (ver >= 4) ? pack_weights_wino64(w.data(), cin, P.cout, pk) : pack_weights_wino(w.data(), cin, P.cout, pk))) { printf("pack failed\n"); return 1; }
     CK(hipMalloc(&wpk, pk.size() * 2)); CK(hipMemcpy(wpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dbias, 256)); CK(hipMalloc(&dscale, 256));
@@ -161,8 +165,8 @@ int main(int argc, char** argv) {
       CK(hipMemcpy(dbias2, bias2.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(dscale2, scale2.data(), 256, hipMemcpyHostToDevice));
       a.f_w = dfw; a.f_bias = dbias2; a.f_scale = dscale2; a.f_act = 1;
     }
-    unsigned long long* dbg; CK(hipMalloc(&dbg, 128)); CK(hipMemset(dbg, 0, 128)); a.dbg = dbg;
-    int rc = (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+    unsigned long long* dbg; CK(hipMalloc(&dbg, 256)); CK(hipMemset(dbg, 0, 256)); a.dbg = dbg;
+    int rc = (ver == 10 ? hcf::wino6::launch(a, ncu, 0) : launch(a, ncu, 0, ver));
     if (rc != 0) { printf("launch failed %d\n", rc); return 1; }
     CK(hipDeviceSynchronize());
     if (check) {
@@ -183,23 +187,43 @@ int main(int argc, char** argv) {
         md = fmax(md, fabs((double)hr[p * P.cout + c] - ho[p * 64 + c])); refmax = fmax(refmax, fabs(hr[p * P.cout + c])); }
       int hovf = 0; CK(hipMemcpy(&hovf, ovf, 4, hipMemcpyDeviceToHost));
       printf("%-34s max|diff| %.3e (ref max %.3f)  %s%s\n", P.name, md, refmax, md <= 4e-6 * refmax ? "OK" : "FAIL", hovf ? "  RANGE FLAG" : "");
+      if (md > 1e-3 * refmax && getenv("W6_VERBOSE")) {          // where are the wrong values?
+        long long nbad = 0; int shown = 0; long long bych[64] = {0};
+        for (long long p = 0; p < npix; ++p) for (int c = 0; c < P.cout; ++c) {
+          const double d = fabs((double)hr[p * P.cout + c] - ho[p * 64 + c]);
+          if (d > 1e-3 * refmax) {
+            ++nbad; ++bych[c];
+            if (shown < 16) { ++shown; printf("    b %lld y %lld x %lld c %d: ref %.5f got %.5f\n", p / (P.H * P.W), (p / P.W) % P.H, p % P.W, c, hr[p * P.cout + c], ho[p * 64 + c]); }
+          }
+        }
+        long long byab[4][4] = {{0}};
+        for (long long p = 0; p < npix; ++p) for (int c = 0; c < P.cout; ++c)
+          if (fabs((double)hr[p * P.cout + c] - ho[p * 64 + c]) > 1e-3 * refmax) ++byab[((p / P.W) % P.H) & 3][(p % P.W) & 3];
+        printf("    by (y & 3, x & 3):");
+        for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) printf(" %lld", byab[i][j]); printf(" |"); }
+        printf("\n    %lld wrong of %lld; per channel:", nbad, npix * P.cout);
+        for (int c = 0; c < P.cout; ++c) printf(" %lld", bych[c]);
+        printf("\n");
+      }
       hipFree(ref);
     } else {
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 10;
-      for (int i = 0; i < 2; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < 2; ++i) (ver == 10 ? hcf::wino6::launch(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e0));
-      for (int i = 0; i < iters; ++i) (ver == 1 ? launch_v1(a, ncu, 0) : ver == 5 ? launch_v5(a, ncu, 0) : (ver == 6 || ver == 7) ? launch_v6(a, ncu, 0, ver - 6) : ver == 10 ? hcf::wino6::launch(a, ncu, 0) : ver >= 8 ? launch_1d(a, ncu, 0, ver) : launch(a, ncu, 0, ver));
+      for (int i = 0; i < iters; ++i) (ver == 10 ? hcf::wino6::launch(a, ncu, 0) : launch(a, ncu, 0, ver));
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * P.cout * (double)npix;
       printf("%-34s %9.1f us  %7.1f TF-eq  (%.3f of 833)\n", P.name, us, fl / us / 1e6, fl / us / 1e6 / 833.3);
+#if defined(W6_PROF)
+      if (ver == 10) { unsigned long long h[16]; CK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost));
+        if (h[13]) { const double life = (double)h[12];
+          printf("    per wave: life %.0f kcyc (%.2f GHz) | top wait %.1f  barrier %.1f  dma issue %.1f  single rows %.1f  row0 %.1f  pair rows %.1f  row1 %.1f  row2 %.1f | exchange %.1f  out0 %.1f  out1+rest %.1f  other %.1f %%\n",
+                 life / 1e3 / h[13], life / (double)h[13] / (us * 1e3 * 12), 100 * h[0] / life, 100 * h[1] / life, 100 * h[2] / life, 100 * h[3] / life, 100 * h[4] / life,
+                 100 * h[5] / life, 100 * h[6] / life, 100 * h[7] / life, 100 * h[8] / life, 100 * h[9] / life, 100 * h[10] / life, 100 * h[11] / life); } }
+#endif
 #if defined(WINO_PROF)
-      if (ver == 5) { unsigned long long h[16]; CK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost));
-        for (int g = 0; g < 2; ++g) if (h[8 * g + 5]) { const double n = (double)h[8 * g + 5] * 12;   /* 12 launches (warm-up + timed) */
-          printf("    group %d, kcycles per wave and launch: rows %.1f  barrier %.1f  positions %.1f  barrier %.1f  epilogue %.1f\n", g,
-                 h[8 * g] / n / 1e3, h[8 * g + 1] / n / 1e3, h[8 * g + 2] / n / 1e3, h[8 * g + 3] / n / 1e3, h[8 * g + 4] / n / 1e3); } }
-      else
       { unsigned long long h[8]; CK(hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost));
         if (h[4]) printf("    per wave: life %.0f kcyc (%.2f GHz)  vmcnt %.1f %%  barrier %.1f %%  setup+issue %.1f %%  loads+transform %.1f %%  epilogue %.1f %%\n",
                          h[2] / 1e3 / h[4], h[2] / (double)h[4] / (us * 1e3), 100.0 * h[0] / h[2], 100.0 * h[1] / h[2], 100.0 * h[5] / h[2], 100.0 * h[6] / h[2], 100.0 * h[3] / h[2]);

@@ -6,8 +6,8 @@
 //   pre-split (both planes x 2^11), V = B^T d B formed in fp32 registers and split there. Full-depth deviation from an fp64
 //   evaluation = plain fp32's (tools/winograd_precision_check.py, profiles/r06_winograd_tiles.txt: the round-5 claim that the
 //   larger tile is numerically out of reach did not survive the measurement).
-//   Matrices: interpolation points 0, +-1, +-2, inf (Lavin & Gray), B^T scaled by 1/4 and G by 4 per side: |V| <= 6.25 max|d|
-//   (F(2x2): 4), |U| <= 16 max|g|.
+//   Matrices: interpolation points 0, +-1, +-2, inf (Lavin & Gray); rows 0, 1, 2, 5 of B^T scaled by 1/4 and of G by 4 (rows 3, 4
+//   as published: their pair then costs four instead of five operations per value): |V| <= 36 max|d| (F(2x2): 4), |U| <= 16 max|g|.
 //
 // Structure (not the F(2x2) kernels' one): a unit of 16 x 32 output pixels = 4 x 8 patches = the 32 columns of the matrix
 // instruction; its 36 positions x 2 channel tiles are 72 accumulators of 16 registers = 57 % of the CU's register file, so
@@ -18,9 +18,11 @@
 //   * with only 32 patches per unit a weight fragment has exactly one consumer in the CU: weights go L2 -> registers
 //     (buffer loads, 1 KB per instruction, three positions ahead), never through LDS;
 //   * LDS holds the fp32 halo image of a 16-channel chunk (18 x 34 pixels, two buffers, filled by buffer_load ... lds one chunk
-//     ahead; 16-byte slots XOR-swizzled so that the patch reads of a 16-lane group hit 16 distinct slots) and, in the epilogue,
-//     the exchange of M through which every lane collects all 36 positions of 4 channels of one patch (two rounds of 144 KB,
-//     one per channel tile; also the transpose that makes 8 consecutive lanes store 128 contiguous bytes of one pixel).
+//     ahead; 16-byte slots XOR-swizzled so that the patch reads of a 16-lane group hit 16 distinct slots), the accumulators of
+//     two of a wave's nine positions (the register file holds 16 of the 18), and, in the epilogue, the exchange of M through
+//     which every lane collects the positions of 4 channels of one patch: four rounds of 72 KB (channel tile x transform rows
+//     0..2 / 3..5 -- the output transform is linear, the second round adds to the first one's partial outputs); also the
+//     transpose that makes 8 consecutive lanes store 128 contiguous bytes of one pixel.
 #pragma once
 #include "hcf_conv_wino.h"
 
@@ -36,14 +38,19 @@ constexpr int MAIN_BYTES = HH * ROWB;            // 36 864 = 36 DMA instructions
 constexpr int SIDE_OFF = MAIN_BYTES;             // side block: halo columns 32..35 (34, 35 dead), 256 bytes per halo row
 constexpr int SIDE_BYTES = 5 * 1024;             // 20 rows (18, 19 dead) = 5 DMA instructions
 constexpr int IMG_BYTES = MAIN_BYTES + SIDE_BYTES;   // 41 984
-constexpr int X_BYTES = 36 * 4096;               // 147 456: one channel tile's M, [pos][q][half][32 patches] x 16 bytes
 constexpr int NRES = 7;                          // positions whose accumulators stay in registers: 14 x 16 = 224 of the 256 AGPRs; the
                                                  // other two positions' accumulators live in LDS during the chunk loop and pass
                                                  // through the remaining 32 (with all 18 resident the allocator spills one to scratch)
-constexpr int ACC8_OFF = 2 * IMG_BYTES;          // 83 968: [position 2][tile 2][reg quad 4][256 threads] x 16 bytes = 64 KB (overlaps
-                                                 // the exchange area: read back at the top of the epilogue)
-constexpr int TAB_OFF = ACC8_OFF + 65536;        // 149 504 (> X_BYTES)
-constexpr int LDS_BYTES = TAB_OFF + 512;         // 150 016
+constexpr int ACC8_OFF = 2 * IMG_BYTES;          // 83 968: [position 2][tile 2][reg quad 4][256 threads] x 16 bytes = 64 KB
+constexpr int X_OFF = ACC8_OFF;                  // the epilogue's exchange buffer (the accumulator slots are read back first):
+constexpr int X_BYTES = 18 * 4096;               // 73 728: HALF a channel tile's M (transform rows 0..2 or 3..5), [pos][q][half][32 patches]
+                                                 // x 16 bytes -- outside the image buffers, so the next unit's first image streams in
+                                                 // during the last chunk and the epilogue as in steady state
+constexpr int TAB_OFF = X_OFF + X_BYTES;         // 157 696: bias * scale, scale * 2^-11
+constexpr int PIX_OFF = TAB_OFF + 512;           // 158 208: [5][256 threads] pixel indices of the DMA cursor's unit (kept out of registers:
+                                                 // carried through the epilogue they are spilled to scratch, and a scratch reload in
+                                                 // front of the DMA issue drains vmcnt -- all prefetched weights -- in every chunk)
+constexpr int LDS_BYTES = PIX_OFF + 5 * 1024;    // 163 328 (of 163 840)
 constexpr int WPOS_BYTES = 4096;                 // per position: [tile 2][plane 2] fragments of 1 KB ([k-half 2][32 oc][8 halves])
 constexpr int WCHUNK_BYTES = 36 * WPOS_BYTES;    // 147 456 per 16-channel chunk
 constexpr float UNSPLIT = 1.f / 2048.f;
@@ -52,7 +59,7 @@ constexpr float UNSPLIT = 1.f / 2048.f;
 static inline bool pack_weights_wino6(const float* w, int cin, int cout, std::vector<uint16_t>& pk) {
 #pragma clang fp contract(off)          /* bit-identical to the device-side rebuild */
   static const double G[6][3] = {{1, 0, 0}, {-2.0 / 3, -2.0 / 3, -2.0 / 3}, {-2.0 / 3, 2.0 / 3, -2.0 / 3},
-                                 {1.0 / 6, 1.0 / 3, 2.0 / 3}, {1.0 / 6, -1.0 / 3, 2.0 / 3}, {0, 0, 4}};
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 4}};
   if (cout != 64 || cin < 16 || (cin & 15)) return false;
   const int nchunk = cin / 16;
   pk.assign(((size_t)nchunk + 1) * (WCHUNK_BYTES / 2), 0);
@@ -81,6 +88,37 @@ static inline bool pack_weights_wino6(const float* w, int cin, int cout, std::ve
 }
 
 #if defined(__HIPCC__)
+#if defined(W6_PROF)        // tools/micro only: shader-clock stamps per phase, accumulated per wave, written through Args::dbg
+#define W6_T(I) { const unsigned long long t_ = __builtin_readcyclecounter(); pw[I] += t_ - pt; pt = t_; }
+#else
+#define W6_T(I)
+#endif
+#ifndef W6_X
+#define W6_X 0
+#endif
+// Guard in front of every position's first matrix instruction. Without it one of this kernel's builds (no residual loads, i.e. a
+// slightly different schedule) returned wrong products for the first MFMA after each VALU-only stretch -- the instruction sat
+// directly behind the split's run of v_fma_mixhi_f16 ... op_sel writes. An empty asm volatile with a memory clobber (a
+// scheduling constraint) is already enough to make it disappear, as is any s_nop; interleaved MFMAs (positions 1, 2 of a row)
+// never showed it. Same family as profiles/r02_fault_rootcause.md (op_sel VALU beside f16 MFMAs). tools/micro checks 23 / 24 /
+// 36 / 38 / 39 are the regression set.
+#ifndef W6_NOPS
+#define W6_NOPS 1
+#endif
+#define W6_STR2(X) #X
+#define W6_STR(X) W6_STR2(X)
+#if W6_NOPS >= 8
+#define W6_GUARD() asm volatile("s_nop 7\n\ts_nop " W6_STR(W6_NOPS - 8) ::: "memory");
+#elif W6_NOPS >= 0
+#define W6_GUARD() asm volatile("s_nop " W6_STR(W6_NOPS) ::: "memory");
+#elif W6_NOPS == -2
+#define W6_GUARD() asm volatile("" ::: "memory");
+#else
+#define W6_GUARD()
+#endif
+#ifndef W6_ABL
+#define W6_ABL 0        // timing-only ablation builds of tools/micro (results wrong by construction): 1 no weight loads in the loop,
+#endif                  // 2 no image DMA in the loop, 4 no MFMAs, 8 no patch reads, 16 no output transform / stores, 32 no LDS accumulators
 using wino::f32x16;
 using wino::f32x4;
 using wino::f16x8;
@@ -89,9 +127,9 @@ using wino::lptr;
 using wino::split8;
 using wino::xcd_remap;
 
-// One half of B^T (scaled by 1/4) applied to five consecutive samples s0..s4 = d[BLK .. BLK + 4] of a 6-vector:
+// One half of B^T (rows 0, 1, 2, 5 scaled by 1/4) applied to five consecutive samples s0..s4 = d[BLK .. BLK + 4] of a 6-vector:
 //   single: BLK 0: xi 0 = d0 - 1.25 d2 + 0.25 d4;  BLK 1: xi 5 = d1 - 1.25 d3 + 0.25 d5      (s0, s2, s4)
-//   pair:   BLK 0: xi 1, 2 = (0.25 d4 - d2) +- (0.25 d3 - d1);  BLK 1: xi 3, 4 = 0.25 (d4 - d2) +- 0.5 (d3 - d1)    (d1..d4)
+//   pair:   BLK 0: xi 1, 2 = (0.25 d4 - d2) +- (0.25 d3 - d1);  BLK 1: xi 3, 4 = (d4 - d2) +- 2 (d3 - d1)    (d1..d4)
 __device__ __forceinline__ float bt_single(float s0, float s2, float s4) { return fmaf(0.25f, s4, fmaf(-1.25f, s2, s0)); }
 template <int BLK>
 __device__ __forceinline__ void bt_pair(float d1, float d2, float d3, float d4, float& o0, float& o1) {
@@ -99,9 +137,30 @@ __device__ __forceinline__ void bt_pair(float d1, float d2, float d3, float d4, 
     const float u = fmaf(0.25f, d4, -d2), v = fmaf(0.25f, d3, -d1);
     o0 = u + v; o1 = u - v;
   } else {
-    const float q = 0.25f * (d4 - d2), e = d3 - d1;
-    o0 = fmaf(0.5f, e, q); o1 = fmaf(-0.5f, e, q);
+    const float q = d4 - d2, e = d3 - d1;
+    o0 = fmaf(2.f, e, q); o1 = fmaf(-2.f, e, q);
   }
+}
+// f16 hi / lo split of 8 fp32 values: wino::split8 on values made opaque first. Left to the compiler, a value that is itself an fma
+// result gets its hi half from a second, mixed-precision copy of that fma (2 instead of 1.5 instructions per value); the
+// conversion written as inline asm (v_cvt_pk_f16_f32) instead gave wrong results in one of four builds of this kernel -- an
+// instruction the hazard recognizer cannot see next to the matrix instructions -- so the conversion stays the compiler's.
+__device__ __forceinline__ void split8p(float (&v)[8], u32x4& h, u32x4& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm("" : "+v"(v[i]));
+#if defined(W6_SPLITNOP)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const wino::f16x2 hh = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+    h[i] = __builtin_bit_cast(uint32_t, hh);
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo) : "v"(h[i]), "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    l[i] = lo;
+  }
+#else
+  split8(v, h, l);
+#endif
 }
 // Block barrier that (i) waits for this wave's outstanding LDS operations first -- a ds_read issued before a bare s_barrier may still
 // be in flight when another wave, released by the barrier, overwrites its source (the epilogue's exchange rounds) -- and (ii) is a
@@ -116,21 +175,6 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int padpix = a.B * H * W;                // out-of-range pixel index: the DMA writes zeros (conv padding / dead pieces)
 
-  // ---- DMA roles. Main block: instruction I = wave + 4 k (k = 0..8) = halo row I >> 1 = 2 k + (wave >> 1), column block I & 1 =
-  // wave & 1 (16 pixels); lane -> 256-byte row r4 = lane >> 4 (pixels 4 xq .. 4 xq + 3, xq = 4 (wave & 1) + r4), physical slot
-  // s = lane & 15 = logical slot ((x & 3) * 4 + part) ^ key, key = (((y >> 2) & 1) << 3) | (xq & 7). The row's key bit is
-  // (k >> 1) & 1: static per unrolled k, so a lane needs two column variants (x, x ^ 2) and the row goes through the scalar offset.
-  const int r4 = lane >> 4, sl = lane & 15;
-  const int xq = 4 * (wave & 1) + r4;
-  const int lg0 = sl ^ (xq & 7);
-  const int hx0 = 4 * xq + (lg0 >> 2), hx1 = 4 * xq + ((lg0 >> 2) ^ 2);
-  const int p16 = (lg0 & 3) * 16;
-  // side block: instruction t = halo rows 4 t .. 4 t + 3 (wave t; wave 0 also t = 4), lane -> row 4 t + r4, logical slot s ^ ((t & 1) << 3)
-  const int lgs0 = sl ^ ((wave & 1) << 3), lgs1 = sl;          // (t = wave, t = 4)
-  const int sx0 = 32 + (lgs0 >> 2), sx1 = 32 + (lgs1 >> 2);
-  const int ps16_0 = (lgs0 & 3) * 16, ps16_1 = (lgs1 & 3) * 16;
-  const int sy0 = 4 * wave + r4, sy1 = 16 + r4;
-
   const int k0 = __builtin_amdgcn_readfirstlane(a.src[0].n >> 4);
   const int k1 = k0 + __builtin_amdgcn_readfirstlane(a.nsrc > 1 ? (a.src[1].n >> 4) : 0);
   const long long npx = (long long)a.B * H * W;
@@ -143,10 +187,17 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
   const int cb0 = __builtin_amdgcn_readfirstlane(a.src[0].c0) * 4, cb1 = __builtin_amdgcn_readfirstlane(a.src[1].c0) * 4,
             cb2 = __builtin_amdgcn_readfirstlane(a.src[2].c0) * 4;
   const int wvo = lane * 16;
+  int* const pixp = reinterpret_cast<int*>(lds + PIX_OFF) + wave * 64 + lane;      // + k * 256
 
-  // DMA cursor (runs one chunk ahead of the matrix loop)
-  int ub = 0, uy0 = 0, ux0 = 0, uc = 0;
-  int pixr0 = padpix, pix0 = padpix, pix1 = padpix, pixs0 = padpix, pixs1 = padpix;
+  // ---- DMA roles. Main block: instruction I = wave + 4 k (k = 0..8) = halo row I >> 1 = 2 k + (wave >> 1), column block I & 1 =
+  // wave & 1 (16 pixels); lane -> 256-byte row r4 = lane >> 4 (pixels 4 xq .. 4 xq + 3, xq = 4 (wave & 1) + r4), physical slot
+  // s = lane & 15 = logical slot ((x & 3) * 4 + part) ^ key, key = (((y >> 2) & 1) << 3) | (xq & 7). The row's key bit is
+  // (k >> 1) & 1: static per unrolled k, so a lane needs two column variants (x, x ^ 2) and the row goes through the scalar offset.
+  // Side block: instruction t = halo rows 4 t .. 4 t + 3 (wave t; wave 0 also t = 4), lane -> row 4 t + r4, logical slot s ^ ((t & 1) << 3).
+  // The five pixel indices of a lane (main row 0 / rows >= 1 in both key variants, two side pieces) are computed per unit from an
+  // opaque copy of the lane id and parked in LDS; the 16-byte part of each piece rides in bits 24..25 of the index.
+  int ub = 0, uy0 = 0, ux0 = 0, uc = 0;          // DMA cursor (runs one chunk ahead of the matrix loop)
+  int pixr0, pix0, pix1, pixs0, pixs1;
 #define W6_SETUP_UNIT(U)                                                                           \
   {                                                                                                \
     const int v_ = a.rev ? nunits - 1 - xcd_remap((U), nunits) : xcd_remap((U), nunits);           \
@@ -154,22 +205,30 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     uy0 = __builtin_amdgcn_readfirstlane(((v_ / tiles_x) % tiles_y) * TH);                         \
     ub = __builtin_amdgcn_readfirstlane(v_ / (tiles_x * tiles_y));                                 \
     uc = 0;                                                                                        \
+    int ln_ = lane;                                                                                \
+    asm volatile("" : "+v"(ln_));                                                                  \
+    const int r4_ = ln_ >> 4, sl_ = ln_ & 15, xq_ = 4 * (wave & 1) + r4_, lg0_ = sl_ ^ (xq_ & 7);   \
+    const int hx0_ = 4 * xq_ + (lg0_ >> 2), hx1_ = 4 * xq_ + ((lg0_ >> 2) ^ 2), part_ = (lg0_ & 3) << 24; \
     const int rowpix_ = (ub * H + uy0) * W;              /* halo row 1 (always inside the image) */ \
-    const int gx0_ = ux0 - 1 + hx0, gx1_ = ux0 - 1 + hx1;                                          \
+    const int gx0_ = ux0 - 1 + hx0_, gx1_ = ux0 - 1 + hx1_;                                        \
     const bool ok0_ = gx0_ >= 0 && gx0_ < W, ok1_ = gx1_ >= 0 && gx1_ < W;                         \
-    pix0 = ok0_ ? rowpix_ + gx0_ : padpix;                                                         \
-    pix1 = ok1_ ? rowpix_ + gx1_ : padpix;                                                         \
-    pixr0 = (ok0_ && uy0 > 0) ? rowpix_ - W + gx0_ : padpix;                                       \
+    pix0 = (ok0_ ? rowpix_ + gx0_ : padpix) | part_;                                               \
+    pix1 = (ok1_ ? rowpix_ + gx1_ : padpix) | part_;                                               \
+    pixr0 = ((ok0_ && uy0 > 0) ? rowpix_ - W + gx0_ : padpix) | part_;                             \
     {                                                                                              \
-      const int gy_ = uy0 - 1 + sy0, gx_ = ux0 - 1 + sx0;                                          \
-      pixs0 = (sx0 < 34 && sy0 < HH && gy_ >= 0 && gy_ < H && gx_ < W) ? (ub * H + gy_) * W + gx_ : padpix; \
+      const int lgs_ = sl_ ^ ((wave & 1) << 3), sx_ = 32 + (lgs_ >> 2), sy_ = 4 * wave + r4_;      \
+      const int gy_ = uy0 - 1 + sy_, gx_ = ux0 - 1 + sx_;                                          \
+      pixs0 = ((sx_ < 34 && gy_ >= 0 && gy_ < H && gx_ < W) ? (ub * H + gy_) * W + gx_ : padpix) | ((lgs_ & 3) << 24); \
     }                                                                                              \
     {                                                                                              \
-      const int gy_ = uy0 - 1 + sy1, gx_ = ux0 - 1 + sx1;                                          \
-      pixs1 = (sx1 < 34 && sy1 < HH && gy_ < H && gx_ < W) ? (ub * H + gy_) * W + gx_ : padpix;    \
+      const int sx_ = 32 + (sl_ >> 2), sy_ = 16 + r4_;                                             \
+      const int gy_ = uy0 - 1 + sy_, gx_ = ux0 - 1 + sx_;                                          \
+      pixs1 = ((sx_ < 34 && sy_ < HH && gy_ < H && gx_ < W) ? (ub * H + gy_) * W + gx_ : padpix) | ((sl_ & 3) << 24); \
     }                                                                                              \
+    pixp[0] = pixr0; pixp[256] = pix0; pixp[512] = pix1; pixp[768] = pixs0; pixp[1024] = pixs1;    \
   }
 #define W6_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds((RS), (lptr)(DST), 16, (VOFF), (SOFF), 0, 0)
+#define W6_VOFF(PIX, CSB) ((int)__umul24((unsigned)(PIX), (unsigned)(CSB)) + (int)(((unsigned)(PIX) >> 24) << 4))
   // image of the cursor's chunk into image buffer IB: 9 main + 1 (wave 0: 2) side instructions per wave
 #define W6_ISSUE_A(IB)                                                                             \
   {                                                                                                \
@@ -179,9 +238,7 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     const int so_ = (sidx_ == 0 ? cb0 + uc * 64 : sidx_ == 1 ? cb1 + (uc - k0) * 64 : cb2 + (uc - k1) * 64); \
     const int wcsb_ = W * csb_;                                                                    \
     const int vpad_ = (int)__umul24((unsigned)padpix, (unsigned)csb_);                             \
-    const int v0_ = (int)__umul24((unsigned)pix0, (unsigned)csb_) + p16;                           \
-    const int v1_ = (int)__umul24((unsigned)pix1, (unsigned)csb_) + p16;                           \
-    const int vr_ = (int)__umul24((unsigned)pixr0, (unsigned)csb_) + p16;                          \
+    const int v0_ = W6_VOFF(pix0, csb_), v1_ = W6_VOFF(pix1, csb_), vr_ = W6_VOFF(pixr0, csb_);    \
     char* const ib_ = lds + (IB) * IMG_BYTES;                                                      \
     _Pragma("unroll") for (int k_ = 0; k_ < 9; ++k_) {                                             \
       const int yrel_ = 2 * k_ + (wave >> 1);                                                      \
@@ -194,20 +251,20 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
         W6_DMA(rsa_, yok_ ? vsel_ : vpad_, yok_ ? so_ + (yrel_ - 1) * wcsb_ : so_, ib_ + (wave + 4 * k_) * 1024); \
       }                                                                                            \
     }                                                                                              \
-    W6_DMA(rsa_, (int)__umul24((unsigned)pixs0, (unsigned)csb_) + ps16_0, so_, ib_ + SIDE_OFF + wave * 1024); \
-    if (wave == 0) W6_DMA(rsa_, (int)__umul24((unsigned)pixs1, (unsigned)csb_) + ps16_1, so_, ib_ + SIDE_OFF + 4 * 1024); \
+    W6_DMA(rsa_, W6_VOFF(pixs0, csb_), so_, ib_ + SIDE_OFF + wave * 1024);                         \
+    if (wave == 0) W6_DMA(rsa_, W6_VOFF(pixs1, csb_), so_, ib_ + SIDE_OFF + 4 * 1024);             \
   }
 
   // ---- patch reads: pixel (row i, column j) of this lane's patch, the k-half's two 16-byte parts (second part: address ^ 16).
   // Columns CB .. CB + 4; a column in the side block (x >= 32: patch column 7, j >= 4) has a 256-byte row stride.
-  // Per chunk: cur[jj] = ca[jj] + the image buffer's offset, made opaque so that the address variants (^ 16, ^ 128, + row) are
+  // Per chunk: cur[jj] = ca[jj] + the image buffer's LDS address, made opaque so that the address variants (^ 16, ^ 128, + row) are
   // formed next to their reads instead of being hoisted out of the chunk loop into ~40 loop-invariant registers (which spill).
   // (columns j <= 3 are never in the side block: their row stride is the constant ROWB and folds into the instruction's offset)
 #define W6_LOAD_PX(D, JJ, I)                                                                       \
   {                                                                                                \
     const int ad_ = (cur[JJ] ^ (((I) >= 4) ? 128 : 0)) + ((CB + (JJ) <= 3) ? (I) * ROWB : ((I) << shs_)); \
-    const f32x4 x0_ = *reinterpret_cast<const f32x4*>(lds + ad_);                                  \
-    const f32x4 x1_ = *reinterpret_cast<const f32x4*>(lds + (ad_ ^ 16));                           \
+    const f32x4 x0_ = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)(unsigned)ad_;   \
+    const f32x4 x1_ = *(const __attribute__((address_space(3))) f32x4*)(uintptr_t)(unsigned)(ad_ ^ 16); \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) { D[k] = x0_[k]; D[4 + k] = x1_[k]; }            \
   }
 
@@ -225,7 +282,7 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     reinterpret_cast<float*>(lds + TAB_OFF)[threadIdx.x] = a.bias[threadIdx.x] * a.scale[threadIdx.x];
     reinterpret_cast<float*>(lds + TAB_OFF)[64 + threadIdx.x] = a.scale[threadIdx.x] * UNSPLIT;
   }
-  char* const acc8p = lds + ACC8_OFF + threadIdx.x * 16;     // + reg quad * 4096
+  char* const acc8p = lds + ACC8_OFF + threadIdx.x * 16;     // + (position * 8 + tile * 4 + reg quad) * 4096
   {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -236,12 +293,12 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
   W6_SETUP_UNIT(u)
   W6_ISSUE_A(0)
   ++uc;
-  W6_LOAD_W(0, 0, 0)
-  W6_LOAD_W(1, 0, 1)
-  W6_LOAD_W(2, 0, 2)
   int g = 0;
-  const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
-  const float slope2 = a.act2 == 1 ? 0.f : a.act2 == 2 ? 0.2f : 1.f;
+#if defined(W6_PROF)
+  unsigned long long pw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long pt0 = __builtin_readcyclecounter();
+  unsigned long long pt = pt0;
+#endif
 
   while (true) {
     f32x16 acc[NRES][2];
@@ -271,26 +328,38 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     }
 
     for (int c = 0; c < nchunk; ++c, ++g) {
-      // this chunk's image was requested a chunk ago, before the 36 weight loads of that chunk, of which the last 12 (three
-      // positions) may still be in flight: loads return in order. (The first chunk of a LATER unit: waited for in the epilogue.)
+      W6_T(11)
+      const bool last = (c + 1 == nchunk);
+      // the chunk's first three positions (ring slots 0..2, free since the previous chunk's last row): requested here, first
+      // used after the single row pass; nothing is in flight across a unit's epilogue
+      if (!(W6_ABL & 1) || g == 0) { W6_LOAD_W(0, c, 0) W6_LOAD_W(1, c, 1) W6_LOAD_W(2, c, 2) }
+      // this chunk's image was requested a chunk ago, before every weight load of that chunk; of all loads only the 12 just
+      // issued may still be in flight: loads return in order. (The first chunk of a LATER unit: requested during the previous
+      // unit's last chunk and waited for in that unit's epilogue, before its first store.)
       if (c > 0 || g == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      W6_BARRIER();                 // image g complete and visible; every wave is through chunk g - 1: buffer (g + 1) & 1 is free
-      if (c + 1 == nchunk) {
+      W6_T(0)
+      if (!last) { pixr0 = pixp[0]; pix0 = pixp[256]; pix1 = pixp[512]; pixs0 = pixp[768]; pixs1 = pixp[1024]; }
+      W6_BARRIER();                                 // image g complete and visible; every wave is through chunk g - 1: buffer (g + 1) & 1 is free
+      W6_T(1)
+      if (last) {
         if (un < nunits) W6_SETUP_UNIT(un)
         else { uc = 0; pixr0 = pix0 = pix1 = pixs0 = pixs1 = padpix; }
       }
-      const bool last = (c + 1 == nchunk);
-      if (!last) { W6_ISSUE_A((g + 1) & 1) ++uc; }  // (the next UNIT's first chunk is issued in the epilogue: LDS is the exchange buffer there)
-      const int cn = last ? 0 : c + 1;              // chunk of the positions prefetched from lp = 6 on
+      if ((!last || un < nunits) && !(W6_ABL & 2)) { W6_ISSUE_A((g + 1) & 1) ++uc; }
+      W6_T(2)
       int cur[5], shs_ = shs;
       {
-        const int ibo = (g & 1) * IMG_BYTES;
+        const int ibo = (g & 1) * IMG_BYTES + (int)(uintptr_t)(lptr)lds;     // (LDS byte address: the array's base is added once per column)
 #pragma unroll
         for (int jj = 0; jj < 5; ++jj) { cur[jj] = ca[jj] + ibo; asm volatile("" : "+v"(cur[jj])); }
         asm volatile("" : "+v"(shs_));
       }
 
+#if (W6_ABL & 4)
+#define W6_MFMA(ACC, WW, VX) asm volatile("" :: "v"(WW), "v"(VX));
+#else
 #define W6_MFMA(ACC, WW, VX) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, WW), __builtin_bit_cast(f16x8, VX), ACC, 0, 0, 0);
+#endif
       // the three positions of local row LA: column pass of T (five columns), split, six MFMAs each, weight prefetch three positions ahead
 #define W6_ROW(LA, T)                                                                              \
   {                                                                                                \
@@ -302,8 +371,16 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     _Pragma("unroll") for (int lb = 0; lb < 3; ++lb) {                                             \
       constexpr int lp_ = (LA) * 3;                                                                \
       u32x4 vh_, vl_;                                                                              \
-      split8(v_[lb], vh_, vl_);                                                                    \
-      if (lp_ + lb < NRES) {                                                                       \
+      split8p(v_[lb], vh_, vl_);                                                                   \
+      W6_GUARD()                                                                                   \
+      if ((lp_ + lb < NRES || (W6_ABL & 32)) && (W6_X & 1)) {                                      \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][1], wf[lb][2], vh_)                           \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][0], wf[lb][0], vh_)                           \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][1], wf[lb][3], vh_)                           \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][0], wf[lb][1], vh_)                           \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][1], wf[lb][2], vl_)                           \
+        W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][0], wf[lb][0], vl_)                           \
+      } else if (lp_ + lb < NRES || (W6_ABL & 32)) {                                               \
         W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][0], wf[lb][0], vh_)                           \
         W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][1], wf[lb][2], vh_)                           \
         W6_MFMA(acc[lp_ + lb < NRES ? lp_ + lb : 0][0], wf[lb][1], vh_)                           \
@@ -331,7 +408,7 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
             *reinterpret_cast<f32x4*>(ap_ + (n_ * 4 + q_) * 4096) = x_;                            \
           }                                                                                        \
       }                                                                                            \
-      if ((LA) < 2) { W6_LOAD_W(lb, c, lp_ + lb + 3) } else { W6_LOAD_W(lb, cn, lb) }              \
+      if (!(W6_ABL & 1) && (LA) < 2) { W6_LOAD_W(lb, c, lp_ + lb + 3) }                            \
     }                                                                                              \
   }
       // T columns: index jj = column CB + jj. bt_single uses columns CB, CB + 2, CB + 4 = jj 0, 2, 4; bt_pair columns 1..4 = jj 1 - CB ..
@@ -346,9 +423,13 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
 #pragma unroll
           for (int k = 0; k < 8; ++k) ts[jj][k] = bt_single(d0[k], d2[k], d4[k]);
         }
+        W6_T(3)
         W6_ROW(0, ts)
+        W6_T(4)
       }
+#if !defined(W6_NOFENCE)
       asm volatile("" ::: "memory");                // (the pair's pixel reads stay behind the single's positions: 80, not 120, live t registers)
+#endif
       {
         float tp[2][5][8];                          // the pair: pixel rows 1..4
 #pragma unroll
@@ -361,19 +442,22 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
 #pragma unroll
           for (int k = 0; k < 8; ++k) bt_pair<RB>(d1[k], d2[k], d3[k], d4[k], tp[0][jj][k], tp[1][jj][k]);
         }
+        W6_T(5)
         W6_ROW(1, tp[0])
+        W6_T(6)
         W6_ROW(2, tp[1])
+        W6_T(7)
       }
 #undef W6_ROW
 #undef W6_MFMA
     }
 
     // ---- epilogue --------------------------------------------------------------------------------------------------------
-    // Exchange of M, one channel tile per round: wave (rb, cb) writes its 9 accumulators of the tile, slot (pos, q, half) x 32
-    // patches (patch slots rotated by 8 q + 4 half: conflict-free 128-bit writes and reads); reader lane (ps, q, hd) of wave w
-    // collects all 36 positions of channels 32 t + 8 q + 4 hd .. + 3 of patch 8 w + ps, applies A^T . A and stores 4 x 4 pixels:
-    // 8 consecutive lanes cover 128 contiguous bytes of a pixel. Order: write 0, read 0, write 1, outputs of tile 0, read 1,
-    // the next unit's first image + weights requested, outputs of tile 1 (m never exceeds 144 registers).
+    // Exchange of M in four rounds (channel tile t) x (transform rows 3 h .. 3 h + 2): the two waves that own those rows write
+    // their 9 positions of the tile, slot (pos, q, half) x 32 patches (patch slots rotated by 8 q + 4 half: conflict-free
+    // 128-bit writes and reads); reader lane (ps, q, hd) of EVERY wave w collects the 18 positions of channels
+    // 32 t + 8 q + 4 hd .. + 3 of patch 8 w + ps, forms R[xi][b] = sum_nu M[xi][nu] A[nu][b] and adds A^T[a][xi] R[xi][b] to its
+    // 4 x 4 outputs; after h = 1: bias / scale / activation / residuals and 16 stores, 8 consecutive lanes = 128 contiguous bytes.
     float chk = 0.f;
     int lane_e = lane;                              // (opaque: the epilogue's lane constants are recomputed per unit, not carried
     asm volatile("" : "+v"(lane_e));                //  through the chunk loop)
@@ -381,6 +465,8 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
     const int patch = 8 * wave + ps, prow = patch >> 3, pcol = patch & 7;
     const int rbase = (qd * 2 + hd) * 512 + ((patch + 8 * qd + 4 * hd) & 31) * 16;
     const int half_e = lane_e >> 5, li_e = lane_e & 31;
+    const float slope = a.act == 1 ? 0.f : a.act == 2 ? 0.2f : 1.f;
+    const float slope2 = a.act2 == 1 ? 0.f : a.act2 == 2 ? 0.2f : 1.f;
     f32x16 a8[9 - NRES][2];                         // the last positions' accumulators come back from LDS (this thread's own slots)
 #pragma unroll
     for (int p_ = 0; p_ < 9 - NRES; ++p_)
@@ -392,105 +478,128 @@ __device__ __forceinline__ void wave_body(const Args& a, const int nunits, char*
 #pragma unroll
           for (int e_ = 0; e_ < 4; ++e_) a8[p_][n_][4 * q_ + e_] = x_[e_];
         }
-    W6_BARRIER();                   // every wave is done with the last chunk's image (and has its a8)
-    f32x4 m[36];
-#define W6_XWRITE(NT)                                                                              \
-  _Pragma("unroll") for (int lp = 0; lp < 9; ++lp) {                                               \
-    const int pos = tidx(RB, lp / 3) * 6 + tidx(CB, lp % 3);                                       \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                \
-      f32x4 v;                                                                                     \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = (lp < NRES) ? acc[lp < NRES ? lp : 0][NT][4 * q + e] : a8[lp < NRES ? 0 : lp - NRES][NT][4 * q + e]; \
-      *reinterpret_cast<f32x4*>(lds + pos * 4096 + q * 1024 + half_e * 512 + ((li_e + 8 * q + 4 * half_e) & 31) * 16) = v; \
-    }                                                                                              \
-  }
-#define W6_XREAD() _Pragma("unroll") for (int pos = 0; pos < 36; ++pos) m[pos] = *reinterpret_cast<const f32x4*>(lds + pos * 4096 + rbase);
-    // outputs of channel tile NT from m: rows R[xi][b] = sum_nu m[xi][nu] A[nu][b], then Y[a][b] = sum_xi A^T[a][xi] R[xi][b]
-#define W6_OUTPUTS(NT, WAIT)                                                                       \
-  {                                                                                                \
-    const int cbq = (NT) * 32 + 8 * qd + 4 * hd;                                                   \
-    const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + cbq * 4);                     \
-    const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + 256 + cbq * 4);               \
-    const bool split_t = ((NT) == 1) && a.out2 != nullptr;   /* second tile routed to its own tensor / activation (fat launches) */ \
-    const float slope_t = split_t ? slope2 : slope;                                                \
-    f32x4 R[6][4];                                                                                 \
-    _Pragma("unroll") for (int xi = 0; xi < 6; ++xi) {                                             \
-      const f32x4* const mm = &m[xi * 6];                                                          \
-      const f32x4 s1 = mm[1] + mm[2], d1 = mm[1] - mm[2], s2 = mm[3] + mm[4], d2 = mm[3] - mm[4];  \
-      R[xi][0] = mm[0] + s1 + s2;                                                                  \
-      R[xi][1] = d1 + 2.f * d2;                                                                    \
-      R[xi][2] = s1 + 4.f * s2;                                                                    \
-      R[xi][3] = d1 + 8.f * d2 + mm[5];                                                            \
-    }                                                                                              \
-    _Pragma("unroll") for (int ob = 0; ob < 4; ++ob) {                                             \
-      const f32x4 s1 = R[1][ob] + R[2][ob], d1 = R[1][ob] - R[2][ob], s2 = R[3][ob] + R[4][ob], d2 = R[3][ob] - R[4][ob]; \
-      f32x4 Y[4];                                                                                  \
-      Y[0] = R[0][ob] + s1 + s2;                                                                   \
-      Y[1] = d1 + 2.f * d2;                                                                        \
-      Y[2] = s1 + 4.f * s2;                                                                        \
-      Y[3] = d1 + 8.f * d2 + R[5][ob];                                                             \
-      _Pragma("unroll") for (int oa = 0; oa < 4; ++oa) {                                           \
-        const int yy = ey0 + 4 * prow + oa, xx = ex0 + 4 * pcol + ob;                              \
-        const bool ok = yy < H && xx < W;                                                          \
-        const size_t pix = (size_t)((size_t)eb * H + (yy < H ? yy : H - 1)) * W + (xx < W ? xx : W - 1); \
-        f32x4 v;                                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-          const float yv = Y[oa][e];                                                               \
-          chk = fmaf(yv, 0.f, chk);                                                                \
-          const float z = fmaf(yv, ms[e], bs[e]);                                                  \
-          v[e] = fmaxf(z, slope_t * z);                                                            \
-        }                                                                                          \
-        if (RES >= 1) {                                                                            \
-          const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.res1 + pix * a.res1_cs + a.res1_c0 + cbq); \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], a.rs1, r1[e]);           \
-        }                                                                                          \
-        if (RES == 2) {                                                                            \
-          const f32x4 r2 = *reinterpret_cast<const f32x4*>(a.res2 + pix * a.res2_cs + a.res2_c0 + cbq); \
-          _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], a.rs2, r2[e]);           \
-        }                                                                                          \
-        if ((WAIT) && ob == 0 && oa == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
-        if (ok && cbq < a.cout) {                                                                  \
-          if (split_t) *reinterpret_cast<f32x4*>(a.out2 + pix * a.out2_cs + a.out2_c0 + (cbq - 32)) = v; \
-          else *reinterpret_cast<f32x4*>(a.out + pix * a.out_cs + a.out_c0 + cbq) = v;             \
-        }                                                                                          \
-      }                                                                                            \
-    }                                                                                              \
-  }
-    W6_XWRITE(0)
-    W6_BARRIER();
-    W6_XREAD()
-    W6_BARRIER();                   // round 0 has been read
-    W6_XWRITE(1)
-    W6_BARRIER();
-    W6_OUTPUTS(0, false)
-    W6_XREAD()
-    W6_BARRIER();                   // the exchange has been read: LDS is free for the next unit's first image
-    {                                               // this thread's ninth-position slots start the next unit at zero
+    W6_T(11)
+#pragma unroll
+    for (int nt_ = 0; nt_ < 2; ++nt_) {
+#if defined(W6_SWAPT)
+      const int nt = 1 - nt_;
+#else
+      const int nt = nt_;
+#endif
+      const int cbq = nt * 32 + 8 * qd + 4 * hd;
+      // this tile's residuals: requested now, used after the two rounds (the pixel addresses are recomputed at the stores)
+#define W6_PIX(OA, OB) ((size_t)((size_t)eb * H + (ey0 + 4 * prow + (OA) < H ? ey0 + 4 * prow + (OA) : H - 1)) * W + (ex0 + 4 * pcol + (OB) < W ? ex0 + 4 * pcol + (OB) : W - 1))
+      f32x4 rv1[4][4], rv2[4][4];
+#pragma unroll
+      for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+          if (RES >= 1) rv1[oa][ob] = *reinterpret_cast<const f32x4*>(a.res1 + W6_PIX(oa, ob) * a.res1_cs + a.res1_c0 + cbq);
+          if (RES == 2) rv2[oa][ob] = *reinterpret_cast<const f32x4*>(a.res2 + W6_PIX(oa, ob) * a.res2_cs + a.res2_c0 + cbq);
+        }
+      f32x4 Y[4][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        W6_BARRIER();                               // the previous round has been read (h = 0, nt = 0: every wave is done with the
+                                                    // last chunk's image and has its own accumulator slots back)
+        if (RB == h) {
+#pragma unroll
+          for (int lp = 0; lp < 9; ++lp) {
+            const int p18 = (tidx(RB, lp / 3) - 3 * RB) * 6 + tidx(CB, lp % 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (lp < NRES) ? acc[lp < NRES ? lp : 0][nt][4 * q + e] : a8[lp < NRES ? 0 : lp - NRES][nt][4 * q + e];
+              *reinterpret_cast<f32x4*>(lds + X_OFF + p18 * 4096 + q * 1024 + half_e * 512 + ((li_e + 8 * q + 4 * half_e) & 31) * 16) = v;
+            }
+          }
+        }
+        W6_BARRIER();
+        f32x4 R[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          f32x4 mm[6];
+#pragma unroll
+          for (int nu = 0; nu < 6; ++nu) mm[nu] = *reinterpret_cast<const f32x4*>(lds + X_OFF + (r * 6 + nu) * 4096 + rbase);
+          const f32x4 s1 = mm[1] + mm[2], d1 = mm[1] - mm[2], s2 = mm[3] + mm[4], d2 = mm[3] - mm[4];
+          R[r][0] = mm[0] + s1 + s2;
+          R[r][1] = d1 + 2.f * d2;
+          R[r][2] = s1 + 4.f * s2;
+          R[r][3] = d1 + 8.f * d2 + mm[5];
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+          if (h == 0) {                             // xi = 0, 1, 2: A^T columns (1, 0, 0, 0), (1, 1, 1, 1), (1, -1, 1, -1)
+            const f32x4 s = R[1][ob] + R[2][ob], d = R[1][ob] - R[2][ob];
+            Y[0][ob] = R[0][ob] + s; Y[1][ob] = d; Y[2][ob] = s; Y[3][ob] = d;
+          } else {                                  // xi = 3, 4, 5: (1, 2, 4, 8), (1, -2, 4, -8), (0, 0, 0, 1)
+            const f32x4 s = R[0][ob] + R[1][ob], d = R[0][ob] - R[1][ob];
+            Y[0][ob] += s; Y[1][ob] += 2.f * d; Y[2][ob] += 4.f * s; Y[3][ob] += 8.f * d + R[2][ob];
+          }
+        }
+      }
+      W6_T(8)
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + cbq * 4);
+      const f32x4 ms = *reinterpret_cast<const f32x4*>(lds + TAB_OFF + 256 + cbq * 4);
+      const bool split_t = (nt == 1) && a.out2 != nullptr;        // second tile routed to its own tensor / activation (fat launches)
+      const float slope_t = split_t ? slope2 : slope;
+      if (!(W6_ABL & 16)) {
+#pragma unroll
+        for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float yv = Y[oa][ob][e];
+              chk = fmaf(yv, 0.f, chk);
+              const float z = fmaf(yv, ms[e], bs[e]);
+              v[e] = fmaxf(z, slope_t * z);
+              if (RES >= 1) v[e] = fmaf(v[e], a.rs1, rv1[oa][ob][e]);
+              if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[oa][ob][e]);
+            }
+            // every load of this wave -- the next unit's first image (requested during the last chunk) and first weights included --
+            // has landed BEFORE the unit's first store is issued: vmcnt counts stores too, a wait at the next chunk's top would sit
+            // out the store acknowledgements
+            if (nt_ == 0 && oa == 0 && ob == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ey0 + 4 * prow + oa < H && ex0 + 4 * pcol + ob < W && cbq < a.cout) {
+              if (split_t) *reinterpret_cast<f32x4*>(a.out2 + W6_PIX(oa, ob) * a.out2_cs + a.out2_c0 + (cbq - 32)) = v;
+              else *reinterpret_cast<f32x4*>(a.out + W6_PIX(oa, ob) * a.out_cs + a.out_c0 + cbq) = v;
+            }
+          }
+      } else {
+        float s_ = 0.f;
+#pragma unroll
+        for (int i_ = 0; i_ < 16; ++i_) s_ += Y[i_ >> 2][i_ & 3][0];
+        chk += s_ * 0.f;
+        if (nt_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      W6_T(9 + nt_)
+    }
+    W6_BARRIER();                                   // the last round has been read: the accumulator slots are this thread's again
+    {
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q_ = 0; q_ < 8 * (9 - NRES); ++q_) *reinterpret_cast<f32x4*>(acc8p + q_ * 4096) = z4;
     }
-    if (un < nunits) {
-      W6_ISSUE_A((g) & 1)
-      ++uc;
-    }
-    W6_LOAD_W(0, 0, 0)                              // (the loop's own prefetch of the next chunk was aimed at chunk 0 already: re-issued
-    W6_LOAD_W(1, 0, 1)                              //  here so that the image DMA above is OLDER than every load in flight at the next
-    W6_LOAD_W(2, 0, 2)                              //  chunk's top -- loads return in order)
-    // (WAIT: the next unit's first image has landed BEFORE this tile's first store is issued -- vmcnt counts stores too, a wait at
-    //  the next chunk's top would sit out the store acknowledgements)
-    W6_OUTPUTS(1, true)
-#undef W6_XWRITE
-#undef W6_XREAD
-#undef W6_OUTPUTS
     if (__any(chk != chk)) {
       if (lane == 0) atomicOr(a.ovf, 1 | (2 << (eb % 30)));       // bit 0 + the unit's sample slot (see hcf_conv_f16x3.hip)
     }
     u = un;
     if (u >= nunits) break;
   }
-#undef W6_BARRIER
+#if defined(W6_PROF)
+  if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
+    for (int i = 0; i < 12; ++i) atomicAdd(a.dbg + i, pw[i]);
+    atomicAdd(a.dbg + 12, __builtin_readcyclecounter() - pt0);
+    atomicAdd(a.dbg + 13, 1ull);
+  }
+#endif
+#undef W6_PIX
 #undef W6_SETUP_UNIT
 #undef W6_DMA
+#undef W6_VOFF
 #undef W6_ISSUE_A
 #undef W6_LOAD_PX
 #undef W6_LOAD_W
