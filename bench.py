@@ -212,6 +212,8 @@ def main():
     import torch.distributed as dist
     from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling, preset, make_params
     from hcflow_amd.dist import gathered_step, timed_region
+    from hcflow_amd import _lib as _hcf_lib
+    lib = _hcf_lib.load()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -300,18 +302,37 @@ def main():
             eng.profile_convs(True)
             keep = {}
 
+            stamps = []
+
             def one(i):
                 keep["out"] = step(i)
+                stamps.append(time.perf_counter())       # (under the default `sync` policy a call returns after its range flag: per-step wall time)
+            # in-kernel clock of the dominant family (block 0 of every 64-channel Winograd launch stamps s_memtime / s_memrealtime):
+            # single-stream regions only -- launches of two streams would interleave their stamps
+            probe = net._nstreams[0] < 2 or B < 4
+            if probe:
+                lib.hcf_debug_clock_probe(1)
             # barrier + synchronize | exactly `steps` steps | barrier + synchronize, MAX over ranks (hcflow_amd/dist.py)
             with PowerSampler(local) as ps, quiet_gc():
+                t_first = time.perf_counter()
                 dt = timed_region(one, steps, first=warmup)
+            clk = None
+            if probe:
+                clk = float(lib.hcf_debug_last_clock_mhz()) or None
+                lib.hcf_debug_clock_probe(0)
             eng.profile_convs(False)
         assert bool(torch.isfinite(keep["out"]).all())
-        roof = roofline_block(eng, mode, steps, dt)
-        roof["power"] = ps.block()
+        roof = roofline_block(eng, mode, steps, dt, clk, ps.block())
+        per = sorted(1e3 * (b - a) for a, b in zip([t_first] + stamps[:-1], stamps))
+        roof["step_ms_host"] = {"p50": round(per[len(per) // 2], 3), "p95": round(per[min(len(per) - 1, int(0.95 * len(per)))], 3),
+                                "max": round(per[-1], 3), "note": "wall time between the returns of consecutive calls inside the timed region"}
         return dt, roof
 
-    def roofline_block(eng, mode, steps, dt):
+    def roofline_block(eng, mode, steps, dt, clk_mhz, power):
+        """`frac` = ALGORITHMIC TFLOP/s of the dominant conv family / the guide's dense peak of the arithmetic it runs on (f16x3:
+        2500 TFLOP/s f16 MFMA; exact: 157.3 fp32 matrix). Beside it: what the matrix cores execute (x 3 split products, / 2.25 for the
+        Winograd families), the same two against the 833 = 2500 / 3 split yardstick of rounds 1-5, and both rescaled to the shader
+        clock the kernel itself ran at (`clock.in_kernel_MHz`: the board holds this workload at its power cap, not at 2.4 GHz)."""
         variants = []
         for label, taps_, nt_, kind_, tkeys_ in VARIANTS[mode]:
             vms, vn, vfl, vby = eng.conv_time(taps_, nt_, kind=kind_)
@@ -324,16 +345,18 @@ def main():
         ms_all, n_all, fl_all, by_all = eng.conv_time(0, 0, reset=True)
         variants.sort(key=lambda v: -v["ms_per_step"])
         if mode == "exact":
-            peak, pnote = PEAK_F32_MFMA_TFLOPS, "fp32 matrix peak (MI355X_MICROARCH.md)"
+            peak, split = PEAK_F32_MFMA_TFLOPS, 1.0
+            pnote = "fp32 matrix peak 157.3 TFLOP/s (MI355X_MICROARCH.md); achieved = algorithmic flops (2*9*Cin*Cout per pixel)"
         else:
-            peak = PEAK_F16_MFMA_TFLOPS / 3
-            pnote = ("f16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product block; achieved counts ALGORITHMIC "
-                     "flops (2*9*Cin*Cout per pixel), the matrix cores execute 3x that (Winograd families: 3 / 2.25 = 1.33x)")
+            peak, split = PEAK_F16_MFMA_TFLOPS, 3.0
+            pnote = ("dense f16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md); achieved = ALGORITHMIC flops (2*9*Cin*Cout per pixel): every fp32 "
+                     "product costs 3 f16 MFMAs (a_hi w_hi + a_hi w_lo + a_lo w_hi), the Winograd families need 2.25x fewer products -- "
+                     "`mfma_executed_frac` is what the matrix cores run, `frac_of_split_yardstick` the 2500 / 3 yardstick of rounds 1-5")
         # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_traffic.py), replayed
         # from profiles/ for EVERY family that has an entry; only valid for the configuration they were collected on
         tj, tfile = None, None
         try:
-            tfile = next(f for f in ("r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json")
+            tfile = next(f for f in ("r06_traffic_pmc.json", "r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json", "r02_traffic_pmc.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", f)))
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
         except (OSError, ValueError, StopIteration):
@@ -341,12 +364,10 @@ def main():
         tvalid = tj is not None and args.preset == "SR_DF2K_4X" and B == 16 and h == 160
         for v in variants:
             wino = "wino" in v["kernel"]
-            v["frac_of_yardstick"] = round(v["tflops"] / peak, 4)
+            v["frac_of_peak"] = round(v["tflops"] / peak, 4)
             if mode != "exact":
-                # the same algorithmic rate against the UN-derated dense f16 MFMA peak, and the share of that peak the matrix
-                # cores actually execute (3 MFMAs per product; the Winograd form needs 2.25x fewer products)
-                v["frac_of_dense_f16_peak"] = round(v["tflops"] / PEAK_F16_MFMA_TFLOPS, 4)
-                v["mfma_executed_frac"] = round(v["tflops"] * (3.0 / 2.25 if wino else 3.0) / PEAK_F16_MFMA_TFLOPS, 4)
+                v["mfma_executed_frac"] = round(v["tflops"] * (3.0 / 2.25 if wino else 3.0) / peak, 4)
+                v["frac_of_split_yardstick"] = round(v["tflops"] * split / peak, 4)
             v["traffic_GB_per_launch"] = None
             try:
                 ents = [tj["kernels"][k] for k in v["_tkeys"] if k in tj["kernels"]] if tvalid else []
@@ -355,12 +376,12 @@ def main():
                                                        sum(e["launches_sampled"] for e in ents) / 1e9, 4)
             except (KeyError, TypeError, ZeroDivisionError):
                 pass
-            # which roofline this family sits closer to: matrix rate against the yardstick, or moved bytes (PMC when available,
+            # which roofline this family sits closer to: executed matrix rate against the peak, or moved bytes (PMC when available,
             # algorithmic otherwise) per measured launch time against the ACHIEVABLE HBM rate
             gb = v["traffic_GB_per_launch"] if v["traffic_GB_per_launch"] is not None else v["algorithmic_GB_per_launch"]
             hbm_frac = gb / (v["avg_launch_us"] * 1e-6) / ACHIEVABLE_HBM_GBS if v["avg_launch_us"] > 0 else 0.0
             v["hbm_frac_of_achievable"] = round(hbm_frac, 4)
-            v["bound"] = "hbm" if hbm_frac > v["frac_of_yardstick"] else "mfma"
+            v["bound"] = "hbm" if hbm_frac > v.get("frac_of_split_yardstick", v["frac_of_peak"]) else "mfma"
         dom = variants[0]                        # the instantiation family with the largest total time IS the dominant kernel
         traffic = dom["traffic_GB_per_launch"]
         tnote = ("GB per launch, REPLAYED from profiles/" + tfile + " (" + tj["source"] + "), not measured in this run") if traffic is not None else \
@@ -369,23 +390,36 @@ def main():
             b_ach, b_peak, b_unit = round(dom["hbm_frac_of_achievable"] * ACHIEVABLE_HBM_GBS, 1), ACHIEVABLE_HBM_GBS, "GB/s"
             b_frac = dom["hbm_frac_of_achievable"]
         else:
-            b_ach, b_peak, b_unit, b_frac = dom["tflops"], round(peak, 1), "TFLOP/s", round(dom["tflops"] / peak, 4)
+            b_ach, b_peak, b_unit, b_frac = dom["tflops"], round(peak, 1), "TFLOP/s", dom["frac_of_peak"]
+        hw = (power or {}).get("sclk_MHz_avg")
+        held = clk_mhz or hw                     # the dominant family's own clock when the probe ran, else the region's hwmon average
+        clock = {"in_kernel_MHz": round(clk_mhz, 0) if clk_mhz else None, "hwmon_sclk_MHz_avg": hw, "nominal_MHz": 2400,
+                 "note": "in_kernel: 100 * s_memtime / s_memrealtime over block 0 of every launch of the 64-channel Winograd kernel in this "
+                         "region (hcf_debug_clock_probe); hwmon: the amdgpu sclk file sampled every 20 ms over the same region (all kernels "
+                         "and the gaps between them). A back-to-back micro of the same kernel holds only ~1.3 GHz (profiles/r05_notes.md "
+                         "section 9): in the pass lighter kernels sit between its launches and the power management averages over them."}
         block = {
             "bound": dom["bound"], "kernel": dom["kernel"], "achieved": b_ach, "peak": b_peak, "unit": b_unit,
             "peak_note": pnote, "frac": b_frac, "traffic": traffic, "traffic_note": tnote,
-            "frac_of_dense_f16_peak": dom.get("frac_of_dense_f16_peak"), "mfma_executed_frac": dom.get("mfma_executed_frac"),
+            "mfma_executed_frac": dom.get("mfma_executed_frac"), "frac_of_split_yardstick": dom.get("frac_of_split_yardstick"),
+            "clock": clock,
+            "frac_at_held_clock": round(b_frac * 2400.0 / held, 4) if (held and dom["bound"] == "mfma") else None,
+            "mfma_executed_frac_at_held_clock": round(dom["mfma_executed_frac"] * 2400.0 / held, 4) if (held and dom.get("mfma_executed_frac")) else None,
+            "split_yardstick_at_held_clock": round(dom["frac_of_split_yardstick"] * 2400.0 / held, 4) if (held and dom.get("frac_of_split_yardstick")) else None,
             "algorithmic_GB_per_launch": dom["algorithmic_GB_per_launch"], "launches": dom["launches_per_step"] * steps,
             "avg_launch_us": dom["avg_launch_us"], "gflop_per_launch": dom["gflop_per_launch"],
             "selection": "instantiation family with the largest total time in the timed region; `bound` = the larger of "
-                         "(algorithmic TFLOP/s / yardstick) and (bytes per launch / launch time / 6.3 TB/s achievable HBM), per family",
+                         "(algorithmic TFLOP/s x split / peak) and (bytes per launch / launch time / 6.3 TB/s achievable HBM), per family",
             "conv_kernels": [{k: v for k, v in x.items() if k != "_tkeys"} for x in variants],
             "all_convs": {"launches": n_all, "ms_per_step": round(ms_all / steps, 3),
                           "tflops": round((fl_all / 1e12) / (ms_all / 1e3), 3) if ms_all > 0 else 0.0,
-                          "frac_of_step_time": round(ms_all / 1e3 / dt, 4)}}
+                          "frac_of_step_time": round(ms_all / 1e3 / dt, 4)},
+            "power": power}
         if args.preset == "SR_DF2K_4X" and h == 160:
             per_gpu = B * steps / dt
             block["whole_pass"] = {
-                "mfma_frac": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / peak, 4),
+                "frac_of_peak": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / peak, 4),
+                "frac_of_split_yardstick": round(per_gpu * GFLOP_PER_IMAGE / 1e3 * split / peak, 4),
                 "vs_fp32_mfma_ceiling": round(per_gpu * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
                 "hbm_frac_layerwise_ideal": round(per_gpu * IDEAL_GB_PER_IMAGE / PEAK_HBM_GBS, 4)}
         return block
@@ -393,6 +427,15 @@ def main():
     default_mode = args.precision                       # = the module's default unless overridden on the command line
     other_mode = "exact" if default_mode == "f16x3" else "f16x3"
     dt, roof = timed(default_mode, args.warmup, args.steps)
+    # the same steps as a plain Python caller runs them: cyclic GC left ON (quiet_gc makes `value` an upper bound for a
+    # caller whose loop pays a generation-2 pause every few hundred calls)
+    gc_on = None
+    if not args.no_single_stream_leg:
+        with torch.no_grad():
+            ks = min(args.steps, 20)
+            dtg = timed_region(lambda i: step(i), ks, first=args.warmup + args.steps)
+        gc_on = {"value": round(world * B * ks / dtg, 4), "unit": "HR images/s", "ms_per_step": round(1e3 * dtg / ks, 3), "steps": ks,
+                 "note": "same workload and timing contract, Python's cyclic collector enabled (the headline regions run with it off)"}
     # The module's default runs a call of >= 4 samples as two half batches on two HIP streams (two engines); their kernels overlap, so
     # HIP-event durations taken in that region do not add up to the step. The roofline block therefore comes from a SECOND timed
     # region of the same steps with the split off (net.set_streams(1)): per-kernel launch durations as rocprofv3 sees them under
@@ -400,15 +443,16 @@ def main():
     single = None
     split_on = net._nstreams[0] >= 2 and B >= 4
     if split_on and not args.no_single_stream_leg:
-        headline_power = roof.get("power")
+        headline_power, headline_steps = roof.get("power"), roof.get("step_ms_host")
         net.set_streams(1)
         try:
             dt1, roof = timed(default_mode, 2, args.steps)
         finally:
             net.set_streams(2)
         single = {"value": round(world * B * args.steps / dt1, 4), "unit": "HR images/s", "ms_per_step": round(1e3 * dt1 / args.steps, 3),
-                  "steps": args.steps, "power": roof.get("power")}
+                  "steps": args.steps, "power": roof.get("power"), "step_ms_host": roof.get("step_ms_host")}
         roof["power"] = headline_power
+        roof["step_ms_host"] = headline_steps
         roof["measured_in"] = ("single-stream timed region (net.set_streams(1), same workload / steps / timing contract: %.2f HR img/s, "
                                "%.2f ms per step): the default's two half-batch streams overlap their kernels, whose event durations "
                                "then do not add up to the step; `power` is the headline (two-stream) region's"
@@ -486,7 +530,7 @@ def main():
                           "note": "value / roofline are the module's default mode; `other_precision` is the same workload, same "
                                   "number of timed steps, on the other conv kernels",
                           "check": check},
-            "roofline": roof, "single_stream": single, "other_precision": other, "cpu_baseline": cpu,
+            "roofline": roof, "single_stream": single, "gc_enabled": gc_on, "other_precision": other, "cpu_baseline": cpu,
         }
         if world == 1 and not args.no_other_configs and args.preset == "SR_DF2K_4X" and B == 16 and h == 160:
             del net, lr, out_all, hr_in
@@ -774,7 +818,7 @@ def cpu_baseline(cfg, params, h, passes):
     import statistics
     import torch
     from oracle import hcflow_oracle as O
-    passes = max(5, int(passes))
+    passes = max(7, int(passes))
     g = torch.Generator().manual_seed(0)
     lr = torch.rand(1, 3, h, h, generator=g)
     fn = O.sr_inverse if cfg.sr else O.rescale_inverse
@@ -785,21 +829,24 @@ def cpu_baseline(cfg, params, h, passes):
     # candidates up to ALL physical cores; the full-size passes use the fastest (more threads only get slower for this
     # op mix: oneDNN convs of 32..64 channels do not scale past ~16 threads; the calibration timings are part of the record)
     cands = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= ncpu})
-    small = torch.rand(1, 3, max(8, h // 4), max(8, h // 4), generator=g)
     best, threads = None, cands[0]
     times, calib = [], {}
     with torch.no_grad():
+        # calibration AT THE WORKLOAD'S SIZE (a 40x40 patch is not the 160x160 problem): one warm pass per candidate;
+        # candidates beyond one that already ran 1.6x slower than the best are skipped -- except all physical cores, always measured
+        torch.set_num_threads(cands[0])
+        fn(lr, params, cfg, 0.0)                           # warm-up (oneDNN primitives, page faults)
         for c in cands:
+            if best is not None and c != phys and calib and min(calib.values()) * 1.6 < list(calib.values())[-1]:
+                continue
             torch.set_num_threads(c)
-            fn(small, params, cfg, 0.0)
             t0 = time.perf_counter()
-            fn(small, params, cfg, 0.0)
+            fn(lr, params, cfg, 0.0)
             t = time.perf_counter() - t0
-            calib[str(c)] = round(t, 4)
+            calib[str(c)] = round(t, 3)
             if best is None or t < best:
                 best, threads = t, c
         torch.set_num_threads(threads)
-        fn(lr[:, :, :h // 2, :h // 2].contiguous(), params, cfg, 0.0)   # warm-up (oneDNN primitives)
         for _ in range(passes):
             t0 = time.perf_counter()
             out = fn(lr, params, cfg, 0.0)
@@ -826,10 +873,13 @@ def cpu_baseline(cfg, params, h, passes):
              "logical_cpus": ncpu, "kind": "port",
              "sample": "oracle/hcflow_oracle.py (PyTorch-CPU fp32, oneDNN): BASELINE config 1, B=1 LR %dx%d, tau=0, median of %d "
                        "timed passes after warm-up, %d threads = the fastest of %s on a host with %d physical cores / %d logical CPUs "
-                       "(calibration on a %dx%d patch: seconds per pass in `thread_calibration_s`)"
-                       % (h, h, passes, threads, cands, phys, ncpu, small.shape[2], small.shape[3]),
+                       "(calibration at the same %dx%d size, one warm pass per candidate: `thread_calibration_s`; "
+                       "`all_physical_cores` is the %d-thread pass of that calibration)"
+                       % (h, h, passes, threads, cands, phys, ncpu, h, h, phys),
              "cpu": cpu_model, "config1_latency_s": round(med, 3), "pass_times_s": [round(t, 3) for t in times],
              "spread_rel": round((max(times) - min(times)) / med, 3), "thread_calibration_s": calib,
+             "all_physical_cores": {"threads": phys, "config1_latency_s": calib.get(str(phys)),
+                                    "value": round(1.0 / calib[str(phys)], 4) if calib.get(str(phys)) else None, "unit": "HR images/s"},
              "batch2_throughput": {"value": round(2.0 / min(t2), 4), "unit": "HR images/s", "pass_times_s": [round(t, 3) for t in t2],
                                    "sample": "same net, B=2 LR %dx%d, tau=0, best of 2 passes, %d threads" % (h, h, threads)},
              "c_port": c_port, "c_net": c_net}, lr, out)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "hcf_op_conv2d", "hcf_op_squeeze2d", "hcf_op_unsqueeze2d", "hcf_op_step_inverse",
     "hcf_op_step_forward_head", "hcf_op_step_forward_couple", "hcf_op_gauss_logp",
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
-    "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz",
+    "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz", "hcf_debug_clock_probe",
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
     "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
@@ -94,6 +94,7 @@ def load() -> C.CDLL:
     lib.hcf_op_set_precision.argtypes = [i32]
     lib.hcf_debug_set_ablation.argtypes = [i32]
     lib.hcf_debug_last_clock_mhz.argtypes = []
+    lib.hcf_debug_clock_probe.argtypes = [i32]
     lib.hcf_debug_last_clock_mhz.restype = C.c_double
     lib.hcf_bench_conv.argtypes = [i32, i32, i32, C.POINTER(i32), i32, i32, i32, i32, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp]

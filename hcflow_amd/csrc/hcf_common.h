@@ -112,6 +112,8 @@ int launch_fcn12(const ConvArgs& a, hipStream_t st);
 size_t pack_conv_weights_wino(const float* w, int cin, int cout, const int* srcs, int nsrc, std::vector<float>& out, int min_cin = -1);
 size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
+int wino_clock_probe(int enable);            // hcf_conv_wino.hip: in-kernel clock probe of the 64-channel kernel
+double wino_clock_probe_mhz();
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st);   // pack rebuilt from device weights
 struct RepackWinoJob { const float* w; void* pk; int cin, cout, cout_tile; long long blk0; };              // blk0: first block of the job (ascending)

@@ -77,6 +77,8 @@ struct Args {
   int rev;                 // walk the units in reverse order (the engine alternates per launch: the consumer starts on what the producer touched last, which the 256 MB MALL still holds)
   int top_wait;            // A/B knob (HCF_WINO_TOP_WAIT=1): the 64-channel kernel waits at the top of every unit's first chunk as before round 5
   unsigned long long* dbg; // WINO_PROF builds: [0] vmcnt wait [1] barrier wait [2] life [3] epilogue [4] samples [5] setup+issue [6] loads+transform
+  unsigned long long* clk; // in-kernel clock probe of the 64-channel kernel (hcf_debug_clock_probe): block 0 adds its life in shader
+                           // cycles (s_memtime) to clk[0] and in 100 MHz ticks (s_memrealtime) to clk[1] ([2], [3]: its start stamps); null: off
 };
 
 // w: PyTorch [cout][cin][3][3] (cin = sum of the source widths, each a multiple of 16). U = G g G^T in double, rows and
@@ -888,6 +890,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   unsigned long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long pw_t0 = __builtin_readcyclecounter();
 #endif
+  if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {      // (start stamps parked in memory: nothing of the probe lives through the loop)
+    a.clk[2] = __builtin_readcyclecounter();
+    a.clk[3] = __builtin_amdgcn_s_memrealtime();
+  }
   f16x8 w11[4];
   W4_SETUP_UNIT(u)
   W4_CHUNK_SCALARS()
@@ -1007,6 +1013,10 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #endif
     u = un;
     if (u >= nunits) break;
+  }
+  if (a.clk != nullptr && blockIdx.x == 0 && tid == 0) {
+    a.clk[0] += __builtin_readcyclecounter() - a.clk[2];       // (launches of one stream are serial: no atomics; the probe is for
+    a.clk[1] += __builtin_amdgcn_s_memrealtime() - a.clk[3];   //  single-stream regions, bench.py's roofline leg)
   }
 #if defined(WINO_PROF)
   if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {

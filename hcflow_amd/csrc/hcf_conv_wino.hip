@@ -94,6 +94,28 @@ int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, voi
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 
+// In-kernel clock probe of the 64-channel Winograd kernel (bench.py: the dominant family's shader clock inside the timed region):
+// per device two counters the kernel's block 0 adds to; enable = allocate / zero, read = synchronise + copy back.
+static unsigned long long* g_wino_clk[64] = {nullptr};
+static bool g_wino_clk_on = false;
+int wino_clock_probe(int enable) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return HCF_ERR_HIP;
+  if (enable) {
+    if (!g_wino_clk[dev] && hipMalloc(&g_wino_clk[dev], 64) != hipSuccess) { g_wino_clk[dev] = nullptr; return HCF_ERR_NOMEM; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_wino_clk[dev], 0, 64) != hipSuccess) return HCF_ERR_HIP;
+  }
+  g_wino_clk_on = enable != 0;
+  return HCF_OK;
+}
+double wino_clock_probe_mhz() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !g_wino_clk[dev]) return 0.0;
+  unsigned long long h[2] = {0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_wino_clk[dev], 16, hipMemcpyDeviceToHost) != hipSuccess || !h[1]) return 0.0;
+  return 100.0 * (double)h[0] / (double)h[1];
+}
+
 // the round-occupancy rule of launch_conv_wino, for callers that must know BEFORE they commit to a schedule (fat launches)
 static int wino_ncu() {
   static int ncu_dev[64] = {0};               // per device (a process may drive several GPUs: nn.DataParallel replicas)
@@ -149,6 +171,10 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   }
   w.ovf = a.ovf;
   w.zeros = reinterpret_cast<const char*>(a.zeros);
+  if (g_wino_clk_on) {
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) == hipSuccess && dev_ >= 0 && dev_ < 64) w.clk = g_wino_clk[dev_];
+  }
   static const int top_wait = getenv("HCF_WINO_TOP_WAIT") ? atoi(getenv("HCF_WINO_TOP_WAIT")) : 0;     // A/B knob, read once
   w.top_wait = top_wait;
   // Consecutive launches walk their units in opposite directions (HCF_WINO_REV=0: all forward): the next conv of a dense block reads

@@ -292,7 +292,11 @@ int hcf_op_conv2d_backward(const float* const* src, const int32_t* src_c, const 
 }
 
 // shader clock (MHz) observed inside the last hcf_bench_conv kernels (s_memtime / s_memrealtime)
-double hcf_debug_last_clock_mhz(void) { return g_last_clock_mhz; }
+double hcf_debug_last_clock_mhz(void) {
+  const double probe = hcf::wino_clock_probe_mhz();       // (hcf_debug_clock_probe: the 64-channel Winograd kernel's own clock since the enable)
+  return probe > 0.0 ? probe : g_last_clock_mhz;
+}
+int hcf_debug_clock_probe(int32_t enable) { return hcf::wino_clock_probe(enable); }
 // timing ablations of the f16x3 kernel (tools/conv_bench.py --ablate); 0 = off
 int hcf_debug_set_ablation(int32_t bits) { hcf::g_f16x3_ablation = bits; return HCF_OK; }
 

@@ -336,6 +336,12 @@ int hcf_aux_conv2d_backward(const float* x, int32_t cs_in, int32_t cin, int32_t 
 int hcf_debug_range_probe(hcf_engine* e, int32_t enable);
 int hcf_debug_range_probe_read(hcf_engine* e, int32_t index, char* key, int32_t key_cap, float* maxima, int32_t* info);
 
+/* Shader clock INSIDE the dominant kernel: while enabled, block 0 of every launch of the 64-channel Winograd kernel adds its life
+ * in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime) to two device counters (scalar registers only, one block);
+ * hcf_debug_last_clock_mhz() synchronises and returns 100 * cycles / ticks since the enable (0 before any launch; without the
+ * probe: the clock of the last hcf_bench_conv call of a TIMERS build). bench.py reads it inside its single-stream timed region
+ * (roofline.clock): the board runs this workload at its power cap, the held clock is part of the roofline fraction. */
+int hcf_debug_clock_probe(int32_t enable);
 double hcf_debug_last_clock_mhz(void);
 /* tools/conv_bench.py --ablate: timing-only ablations of the f16x3 kernel (results invalid); 0 = off */
 int hcf_debug_set_ablation(int32_t bits);
