@@ -302,8 +302,14 @@ def gen_rgrad_fixture(name, preset_name, ref_sr, B, h, w, seed, tau):
 
 
 def gen_metrics_fixture():
-    """Validation metrics: the reference's imresize (pure numpy), calculate_psnr and bgr2ycbcr run here; the
-    cv2-based SSIM cannot (no OpenCV in this image) and stays unpinned (oracle/metrics_oracle.py)."""
+    """Validation metrics: the reference's imresize (pure numpy), calculate_psnr and bgr2ycbcr run here as they are. Its SSIM
+    (utils/util.py:914-955) calls two OpenCV primitives and this image has no OpenCV: the reference's OWN ssim / calculate_ssim /
+    calculate_psnr_ssim are run against a stand-in `cv2` module that implements exactly those two from OpenCV's documentation --
+    getGaussianKernel(ksize, sigma > 0) = exp(-(i - (ksize - 1) / 2)^2 / (2 sigma^2)) normalised to sum 1, as a ksize x 1 float64
+    column; filter2D(src, -1, kernel) = correlation, anchor at the kernel centre, BORDER_REFLECT_101 (scipy.ndimage.correlate,
+    mode="mirror") -- so everything else of the function (constants, crop, maps, means, channel and Y handling, crop_border) is
+    the reference's code, and the fixture also records that the border rule cannot matter (`ssim_border_dependence_*`: the
+    values with a zero border instead)."""
     import types
     import importlib.util as ilu
     spec0 = ilu.spec_from_file_location("ref_utils_imresize", os.path.join(REF, "utils", "imresize.py"))
@@ -324,6 +330,17 @@ def gen_metrics_fixture():
     spec2 = ilu.spec_from_file_location("ref_data_util", os.path.join(REF, "data", "util.py"))
     du = ilu.module_from_spec(spec2)
     spec2.loader.exec_module(du)
+    from scipy import ndimage
+    cv2s = sys.modules["cv2"]
+
+    def _gk(ksize, sigma):
+        i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+    border = {"mode": "mirror"}
+    cv2s.getGaussianKernel = _gk
+    cv2s.filter2D = lambda src, ddepth, kernel: ndimage.correlate(np.asarray(src, dtype=np.float64), kernel, **border)
+    ru.cv2 = cv2s
     rs = np.random.RandomState(7)
     out = {}
     for tag, (h, w) in {"a": (48, 64), "b": (37, 53)}.items():
@@ -340,6 +357,15 @@ def gen_metrics_fixture():
                                                             du.bgr2ycbcr(s8.copy(), only_y=True) * 255))
         out["down4_" + tag] = imresize(g8.astype(np.float64), 0.25)
         out["down2_" + tag] = imresize(s8.astype(np.float64), 0.5)
+        # SSIM by the reference's functions over the documented cv2 stand-in (see the docstring)
+        border.update(mode="mirror")
+        out["ssim_" + tag] = np.float64(ru.calculate_ssim(g8 * 255, s8 * 255))
+        for cb in (0, 4):     # (copies: the reference's bgr2ycbcr scales a float input IN PLACE, data/util.py:209-230)
+            out["psnr_ssim_cb%d_%s" % (cb, tag)] = np.asarray(ru.calculate_psnr_ssim(g8.copy(), s8.copy(), crop_border=cb), dtype=np.float64)
+        border.update(mode="constant", cval=0.0)
+        out["ssim_border_dependence_" + tag] = np.float64(abs(ru.calculate_ssim(g8 * 255, s8 * 255) - float(out["ssim_" + tag])))
+        border.pop("cval")
+        border.update(mode="mirror")
     path = os.path.join(HERE, "metrics.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

@@ -27,6 +27,10 @@ def test_psnr_ssim_matches_reference_and_oracle(tag, crop):
     if crop == 0:                                           # pinned by the reference's own functions
         assert abs(r["psnr"] - float(g["psnr_" + tag])) <= 1e-9
         assert abs(r["psnr_y"] - float(g["psnr_y_" + tag])) <= 1e-9
+    # all four by the reference's calculate_psnr_ssim (utils/util.py:958-982), run over the documented cv2 stand-in of make_golden.py
+    ref4 = g["psnr_ssim_cb%d_%s" % (crop, tag)]
+    for k, w in zip(["psnr", "ssim", "psnr_y", "ssim_y"], ref4):
+        assert abs(r[k] - float(w)) <= 1e-9 * max(1.0, abs(float(w))), (k, r[k], float(w))
     wb = M.calculate_psnr_ssim(M.imresize(g8, 0.25), M.imresize(s8, 0.25), 0)
     for k, w in zip(["bic_psnr", "bic_ssim", "bic_psnr_y", "bic_ssim_y"], wb):
         if np.isnan(w):                                     # 10-row image: the 11x11 window has no valid position

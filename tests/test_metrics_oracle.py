@@ -1,8 +1,10 @@
 """The metrics oracle (oracle/metrics_oracle.py) against the reference's own functions (tests/golden/metrics.npz:
-imresize, calculate_psnr, bgr2ycbcr). OpenCV is absent here, so SSIM (utils/util.py:914-934) cannot be run from the reference;
-it is pinned analytically instead: only the interior [5:-5, 5:-5] of cv2.filter2D is used (border handling never enters), so
-the result is fully determined by the documented cv2.getGaussianKernel formula + plain correlation; a brute-force loop
-evaluation and a closed-form case check the restatement."""
+imresize, calculate_psnr, bgr2ycbcr, and -- round 6 -- ssim / calculate_ssim / calculate_psnr_ssim). OpenCV is absent here; the
+reference's SSIM functions were run by tests/golden/make_golden.py over a stand-in `cv2` module that implements only
+getGaussianKernel and filter2D (BORDER_REFLECT_101) from OpenCV's documentation, so constants, crop, maps, means, channel / Y
+handling and crop_border are the reference's code; the fixture also records that the border rule cannot enter
+(`ssim_border_dependence_*` = 0: only filter2D(...)[5:-5, 5:-5] is used). A brute-force loop evaluation and a closed-form case
+check the two stand-in primitives' restatement independently."""
 import math
 
 import numpy as np
@@ -22,6 +24,18 @@ def test_psnr_y_and_imresize_match_reference(tag):
     assert abs(M.calculate_psnr(M.bgr2y(g8) * 255, M.bgr2y(s8) * 255) - float(g["psnr_y_" + tag])) <= 1e-9
     assert np.abs(M.imresize(g8, 0.25) - g["down4_" + tag]).max() <= 1e-12
     assert np.abs(M.imresize(s8, 0.5) - g["down2_" + tag]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_ssim_matches_the_references_functions(tag):
+    g = load_golden("metrics")
+    g8, s8 = M.tensor2img(g["gt_" + tag]) / 255.0, M.tensor2img(g["sr_" + tag]) / 255.0
+    assert abs(M.calculate_ssim(g8 * 255, s8 * 255) - float(g["ssim_" + tag])) <= 1e-12
+    for cb in (0, 4):
+        want = g["psnr_ssim_cb%d_%s" % (cb, tag)]
+        got = M.calculate_psnr_ssim(g8, s8, cb)
+        assert np.abs(np.asarray(got) - want).max() <= 1e-10, (cb, got, want)
+    assert float(g["ssim_border_dependence_" + tag]) == 0.0       # zero border instead of REFLECT_101: the same value
 
 
 def test_ssim_sanity():
