@@ -116,7 +116,13 @@ int wino_clock_probe(int enable);            // hcf_conv_wino.hip: in-kernel clo
 double wino_clock_probe_mhz();
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st);   // pack rebuilt from device weights
-struct RepackWinoJob { const float* w; void* pk; int cin, cout, cout_tile; long long blk0; };              // blk0: first block of the job (ascending)
+// One Winograd pack rebuilt from device weights. Element (oc, ic) of the PACK comes from row oc of `w` (oc < split) or row oc - split
+// of `w2`, rows `ld` / `ld2` floats apart (0: cin * 9, a plain [cout][cin][3][3] tensor), input channel ic of the pack = channel
+// ic of the row (z1_pad == 0) or, for the packs whose first source is z1 zero-padded to z1_pad channels: ic < z1_n -> ic, ic < z1_pad
+// -> zero, else ic - z1_pad + z1_n. The derived packs of hcf_engine.hip (fat dense-block pairs, padded-z1 FCN / DenseBlock convs) are
+// all of this shape. frag1x1 != 0: the job is the lane-order pack of a 1x1 64 -> 64 layer instead (wino::pack_weights_1x1_frag).
+struct RepackWinoJob { const float* w; void* pk; int cin, cout, cout_tile; long long blk0;                             // blk0: first block of the job (ascending)
+                       const float* w2; int split, ld, ld2, z1_n, z1_pad, frag1x1; };
 int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long nblocks, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------

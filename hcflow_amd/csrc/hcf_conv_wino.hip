@@ -40,11 +40,29 @@ size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out) {
 
 // Device-side rebuild of a Winograd pack from the PyTorch-layout weight in device memory (after an optimiser step): the same
 // arithmetic as wino::pack_weights_wino, one thread per (output channel, input channel).
-__device__ __forceinline__ void repack_wino_one(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk, int idx) {
+__device__ __forceinline__ void repack_wino_one(const RepackWinoJob& jb, int idx) {
 #pragma clang fp contract(off)
+  const int cin = jb.cin, cout = jb.cout, cout_tile = jb.cout_tile;
+  uint16_t* __restrict__ pk = reinterpret_cast<uint16_t*>(jb.pk);
+  if (jb.frag1x1) {                              // lane-order pack of a 1x1 64 -> 64 layer: idx = (mt, ks, lane, e)
+    if (idx >= 4096) return;
+    const int e = idx & 7, ln = (idx >> 3) & 63, ks = (idx >> 9) & 3, mt = idx >> 11;
+    const int oc = mt * 32 + (ln & 31), ic = 16 * ks + 8 * (ln >> 5) + e;
+    const float x = jb.w[oc * 64 + ic];
+    const _Float16 hi = (_Float16)x;
+    const _Float16 p0 = (_Float16)((float)hi * 2048.f), p1 = (_Float16)((x - (float)hi) * 2048.f);
+    const size_t o = ((size_t)((mt * 4 + ks) * 2 + 0) * 64 + ln) * 8 + e;
+    pk[o] = __builtin_bit_cast(uint16_t, p0);
+    pk[o + 512] = __builtin_bit_cast(uint16_t, p1);
+    return;
+  }
   if (idx >= cin * cout) return;
   const int oc = idx / cin, ic = idx - oc * cin;
-  const float* g = w + (size_t)idx * 9;
+  const int ld = jb.ld ? jb.ld : cin * 9, ld2 = jb.ld2 ? jb.ld2 : cin * 9;
+  const float* row = (!jb.w2 || oc < jb.split) ? jb.w + (size_t)oc * ld : jb.w2 + (size_t)(oc - jb.split) * ld2;
+  const int col = jb.z1_pad == 0 ? ic : (ic < jb.z1_n ? ic : ic < jb.z1_pad ? -1 : ic - jb.z1_pad + jb.z1_n);
+  float g[9];
+  for (int t = 0; t < 9; ++t) g[t] = col >= 0 ? row[(size_t)col * 9 + t] : 0.f;
   const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
   double t[4][3], U[4][4];
   for (int i = 0; i < 4; ++i)
@@ -66,8 +84,8 @@ __device__ __forceinline__ void repack_wino_one(const float* __restrict__ w, int
     }
 }
 
-__global__ __launch_bounds__(256) void repack_wino_kernel(const float* __restrict__ w, int cin, int cout, int cout_tile, uint16_t* __restrict__ pk) {
-  repack_wino_one(w, cin, cout, cout_tile, pk, blockIdx.x * 256 + threadIdx.x);
+__global__ __launch_bounds__(256) void repack_wino_kernel(const RepackWinoJob j) {
+  repack_wino_one(j, blockIdx.x * 256 + threadIdx.x);
 }
 // every Winograd pack of the net in one launch (the training step's refresh: ~500 packs): block -> job by binary search over blk0
 __global__ __launch_bounds__(256) void repack_wino_batch_kernel(const RepackWinoJob* __restrict__ jobs, int njobs) {
@@ -78,7 +96,7 @@ __global__ __launch_bounds__(256) void repack_wino_batch_kernel(const RepackWino
     if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid;
   }
   const RepackWinoJob j = jobs[lo];
-  repack_wino_one(j.w, j.cin, j.cout, j.cout_tile, reinterpret_cast<uint16_t*>(j.pk), (int)(blk - j.blk0) * 256 + threadIdx.x);
+  repack_wino_one(j, (int)(blk - j.blk0) * 256 + threadIdx.x);
 }
 int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long nblocks, hipStream_t st) {
   if (!jobs_dev || njobs < 1 || nblocks < 1 || nblocks > 0x7fffffffLL) return HCF_ERR_ARG;
@@ -89,8 +107,10 @@ int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long
 // cout_tile = the pack's width (32 / 64; > cout for the zero-padded tiles, whose extra rows stay as the host pack left them)
 int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st) {
   if (!w_dev || !pk || cin < 16 || (cin & 15) || (cout_tile != 32 && cout_tile != 64) || cout < 1 || cout > cout_tile) return HCF_ERR_ARG;
-  hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, w_dev, cin, cout, cout_tile,
-                     reinterpret_cast<uint16_t*>(pk));
+  RepackWinoJob j;
+  memset(&j, 0, sizeof(j));
+  j.w = w_dev; j.pk = pk; j.cin = cin; j.cout = cout; j.cout_tile = cout_tile; j.split = cout;
+  hipLaunchKernelGGL(repack_wino_kernel, dim3((unsigned)((cin * cout + 255) / 256)), dim3(256), 0, st, j);
   return hipGetLastError() == hipSuccess ? HCF_OK : HCF_ERR_HIP;
 }
 

@@ -233,3 +233,59 @@ def test_engine_runs_16_channel_dense_blocks_as_fat_pairs():
     assert maxdiff(lr_f, lr_e) <= 1.0 / 255 + 1e-6                       # quantised LR^: at most a single level flips
     assert float(((lr_f - lr_e).abs() > 1e-6).float().mean()) < 0.01
     assert maxdiff(rec_f, rec_e) <= 2e-5 * max(1.0, float(rec_e.abs().max()))
+
+
+def test_inference_after_an_optimiser_step_keeps_the_fat_schedule():
+    """train_HCFlow.py:208-305 validates between optimiser steps. After `opt.step()` the engine refreshes its packs on the device
+    (hcf_refresh_from_device); round 6 rebuilds the DERIVED Winograd packs there too -- fat dense-block pairs, the conditional
+    FCN's padded conv1 + conv2 fragment pack -- so the following eval-mode inverse call (i) still takes the fat launches (conv
+    profile kinds 7 and 6) and (ii) equals a FRESH module fed the updated parameters through the host path (hcf_finalize)."""
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import eps_shapes
+    from tests.test_gpu_backward import _fresh_sr
+    from tests.util import maxdiff
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(19)
+    B, size = 2, 40
+    hr = torch.rand(B, 3, 4 * size, 4 * size, generator=g).cuda()
+    lr = torch.rand(B, 3, size, size, generator=g).cuda()
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    eps = [torch.randn(s, generator=g).cuda() * 0.8 for s in eps_shapes(cfg, B, size, size)]
+    opt = torch.optim.SGD(net.parameters(), lr=1e-7)
+    for _ in range(3):                                  # step 1: host path; steps 2, 3 see a device refresh
+        opt.zero_grad()
+        _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+        nll.backward()
+        opt.step()
+    net.eval()
+    net.set_precision("f16x3")
+    try:
+        with torch.no_grad():
+            a = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)      # refresh happens here
+            eng = net.engine()
+            eng.profile_convs(True)
+            b = net.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            n_fat = eng.conv_time(9, 0, kind=7)[1]
+            n_fcn = eng.conv_time(9, 0, kind=6, reset=True)[1]
+            eng.profile_convs(False)
+        assert net._engines[0]["ptrs"] is not None       # (the device-side path, not a host re-finalise)
+        assert n_fat > 0 and n_fcn > 0, (n_fat, n_fcn)
+        assert torch.equal(a, b)
+        ref = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+        for m in ref.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        ref = ref.to("cuda:0").eval().set_precision("f16x3")
+        with torch.no_grad():
+            c = ref.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            e2 = ref.engine()
+            e2.profile_convs(True)
+            ref.reverse_flow_diracLR(lr, None, None, eps_std=0.8, eps=eps, clamp=False)
+            assert e2.conv_time(9, 0, kind=7, reset=True)[1] == n_fat       # the same schedule on both sides
+            e2.profile_convs(False)
+        # (the device refresh evaluates exp(logs) with the GPU's expf, the host path with libm: ~1 ulp in the epilogue scales)
+        assert maxdiff(a, c) <= 2e-5 * max(1.0, float(c.abs().max()))
+    finally:
+        net.set_precision("exact")
