@@ -289,3 +289,55 @@ def test_inference_after_an_optimiser_step_keeps_the_fat_schedule():
         assert maxdiff(a, c) <= 2e-5 * max(1.0, float(c.abs().max()))
     finally:
         net.set_precision("exact")
+
+
+def test_in_place_updates_of_a_rescaling_net_keep_its_winograd_schedules():
+    """The rescaling nets' derived packs -- 16-channel fat pairs (one 32-channel launch + a zero-padded completion) and the
+    DenseBlock convs over [z1 padded | growth] -- are rebuilt on the device as well: after an in-place update of every parameter
+    the round trip equals a FRESH module's and the launch mix (Winograd kinds 4 / 7) is the same as before the update."""
+    from hcflow_amd import HCFlowNet_Rescaling
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, maxdiff
+    cfg = preset("Rescaling_4X_tiny")
+    net = HCFlowNet_Rescaling(opt=cfg.to_opt(), step=0)
+    net.load_state_dict(cached_params("Rescaling_4X_tiny", 13), strict=True)
+    for m in net.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    net = net.to("cuda:0").eval().set_precision("f16x3")
+    g = torch.Generator().manual_seed(23)
+    hr = torch.rand(2, 3, 96, 128, generator=g).cuda()
+
+    def roundtrip(n):
+        lr_hat, _, _ = n(hr=hr, reverse=False)
+        lrq = (torch.clamp(lr_hat, 0, 1) * 255.).round() / 255.
+        return lr_hat, n(lr=lrq, eps_std=0.0, reverse=True)
+
+    def mix(n):
+        e = n.engine()
+        e.profile_convs(True)
+        roundtrip(n)
+        r = (e.conv_time(9, 0, kind=4)[1], e.conv_time(9, 0, kind=7, reset=True)[1])
+        e.profile_convs(False)
+        return r
+    with torch.no_grad():
+        roundtrip(net)                                   # host path, binds pointers
+        before = mix(net)
+        for p in net.parameters():
+            if p.requires_grad:
+                p.mul_(1.0 + 1e-3)                       # in place: only _version moves -> device-side refresh
+        a = roundtrip(net)
+        after = mix(net)
+    assert net._engines[0]["ptrs"] is not None
+    assert before[0] > 0 and before == after, (before, after)
+    ref = HCFlowNet_Rescaling(opt=cfg.to_opt(), step=0)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    for m in ref.modules():
+        if "ActNorm" in type(m).__name__:
+            m.inited = True
+    ref = ref.to("cuda:0").eval().set_precision("f16x3")
+    with torch.no_grad():
+        b = roundtrip(ref)
+        assert mix(ref) == after
+    for x, y in zip(a, b):
+        assert maxdiff(x, y) <= 2e-5 * max(1.0, float(y.abs().max()))
