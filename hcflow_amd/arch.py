@@ -22,6 +22,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -389,14 +390,22 @@ class _RescaleForwardStep(torch.autograd.Function):
 
 
 _POOL = []
+_POOL_LOCK = threading.Lock()
 
 
 def _enqueue_pool():
     """One helper thread per process that enqueues the second half batch of a split inference call (see _run_checked)."""
     if not _POOL:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="hcflow-enqueue"))
+        with _POOL_LOCK:                 # (nn.DataParallel runs its replicas on parallel threads: one executor, not one per first caller)
+            if not _POOL:
+                from concurrent.futures import ThreadPoolExecutor
+                _POOL.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix="hcflow-enqueue"))
     return _POOL[0]
+
+
+def _capturing() -> bool:
+    """torch.cuda.is_current_stream_capturing() that answers False on a host without a GPU (the call then fails loudly further down)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 class _StaleParameters(Exception):
@@ -404,7 +413,7 @@ class _StaleParameters(Exception):
     the enqueued pass has been drained and the call is redone on the checked path."""
 
 
-def _split_threaded(lr_pixels: int) -> bool:
+def _split_threaded() -> bool:
     """Second half of a split call enqueued by the helper thread? Default: yes (Face x8 at LR 20 x 20: 1 542 against 1 403 img/s with
     one thread enqueueing both halves, 1 416 unsplit; the -25 % once measured for this case was a garbage-collection pause inside
     an 8-call timing loop). HCF_SPLIT_THREADED=0 turns it off (A/B knob)."""
@@ -591,10 +600,12 @@ class _EngineModule(nn.Module):
         if slot == 0:
             self.__dict__["_call_stamp"] = None
             self.__dict__["_deferred"] = None
+            self.__dict__["_ran_unverified"] = False
         if (defer and slot == 0) or (same_call and self.__dict__.get("_deferred") is not None):
             if ent["stamp"] is not None and ent.get("stable"):
                 if slot == 0:
                     self.__dict__["_deferred"] = []
+                    self.__dict__["_ran_unverified"] = True      # until _run_checked has compared the stamps
                 self.__dict__["_deferred"].append(ent)
                 return ent["engine"], idx
         # (same_call: the twin engine of a split call is looked up right after the primary one -- the ~1 ms walk over the 1 500-1 900
@@ -617,10 +628,16 @@ class _EngineModule(nn.Module):
             # The device-side refresh re-reads every PARAMETER; the LU-decomposed invertible convs' fixed buffers (p, sign_s:
             # Permutations.py:54-55) are captured by hcf_finalize only. A load_state_dict / in-place write that changes them
             # (a checkpoint's pivoting differs from the random init's) takes the full host path below.
-            lu_stamp = tuple((p.data_ptr(), p._version) for key, p in named
-                             if key.endswith(".permute.p") or key.endswith(".permute.sign_s"))
+            # Compared by CONTENT when the cheap (address, version) stamp moved: nn.DataParallel hands replicas on devices >= 1
+            # freshly broadcast buffer tensors at every forward -- by address alone each of their calls took the ~1.7 s host path.
+            lu_t = [p for key, p in named if key.endswith(".permute.p") or key.endswith(".permute.sign_s")]
+            lu_stamp = tuple((p.data_ptr(), p._version) for p in lu_t)
             lu_same = ent.get("lu_stamp") == lu_stamp
+            if not lu_same and ent.get("lu_copy") is not None and len(ent["lu_copy"]) == len(lu_t):
+                lu_same = all(a.shape == b.shape and a.device == b.device and bool(torch.equal(a, b)) for a, b in zip(ent["lu_copy"], lu_t))
             ent["lu_stamp"] = lu_stamp
+            if not lu_same or ent.get("lu_copy") is None:
+                ent["lu_copy"] = [p.detach().clone() for p in lu_t]
             if on_dev and lu_same and ent.get("ptrs") == ptrs:
                 # same tensors, new contents (optimiser step): rewrite the packs on the device
                 with torch.cuda.device(idx):
@@ -690,8 +707,7 @@ class _EngineModule(nn.Module):
             else:
                 # two half batches on two side streams. ``threaded`` (large samples): the second half's launches are enqueued by a
                 # helper thread WHILE this thread enqueues the first half's (ctypes drops the GIL inside the C call): config 2
-                # +4.5 % instead of +2.8 % (profiles/r05_notes.md section 4). At small grids (Face x8) the hand-over and the two
-                # threads' contention inside the HIP runtime cost more than they bring (-25 %): there the halves are enqueued in turn
+                # +4.5 % instead of +2.8 %, Face x8 +9 % (profiles/r05_notes.md sections 4, 11); HCF_SPLIT_THREADED=0: enqueued in turn
                 for _, _, _, st_ in parts:
                     st_.wait_stream(cur)                          # the inputs were produced on the caller's stream
                 (e0, lo0, hi0, s0), (e1, lo1, hi1, s1) = parts
@@ -721,6 +737,7 @@ class _EngineModule(nn.Module):
                     for e_, _, _, _ in parts:
                         e_.check_range_samples()                  # (whatever it flagged is dropped with it)
                     raise _StaleParameters()
+                self.__dict__["_ran_unverified"] = False          # verified: from here on an error is the call's own
             if self._precision[0] != "f16x3" or self._range_check[0] != "sync":
                 return
             flagged, any_over = [], False
@@ -859,11 +876,15 @@ class _EngineModule(nn.Module):
         self._check_inference(reverse=True)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # follows torch.manual_seed
-        if not self.training:
+        if not self.training and not _capturing():      # (a stale pass is drained with a stream sync: never while capturing)
             try:
                 return self._inverse_pass(lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer=True)
             except _StaleParameters:
                 pass                                               # parameters changed since the last call: the checked path
+            except _lib.HcfError:
+                if not self.__dict__.pop("_ran_unverified", False):
+                    raise
+                # an error of a pass that ran on UNVERIFIED packs is not the caller's: the checked path decides
         return self._inverse_pass(lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer=False)
 
     def _inverse_pass(self, lr, eps_std, eps, clamp, seed, sample_offset, cache_cond, defer):
@@ -929,7 +950,7 @@ class _EngineModule(nn.Module):
         def one_sample(b):
             return run(eng, b, b + 1, self._stream(idx), flags & ~(_lib.FLAG_KEEP_COND | _lib.FLAG_REUSE_COND))
         self._run_checked(eng, idx, run, "hcf_inverse", batch=B, call_sample=None if cache_cond else one_sample,
-                          parts=parts, threaded=_split_threaded(h * w))
+                          parts=parts, threaded=_split_threaded())
         return out
 
     # convenience for benchmarks / multi-GPU sharding
@@ -1034,11 +1055,15 @@ class HCFlowNet_Rescaling(_EngineModule):
                     self.normal_flow_diracLR(hr)
             return _RescaleForwardStep.apply(self, self._prep(hr, dev), bool(clamp), *self._params())
         self._check_inference()
-        if not self.training:
+        if not self.training and not _capturing():      # (a stale pass is drained with a stream sync: never while capturing)
             try:
                 return self._forward_pass(hr, clamp, defer=True)
             except _StaleParameters:
                 pass                                               # parameters changed since the last call: the checked path
+            except _lib.HcfError:
+                if not self.__dict__.pop("_ran_unverified", False):
+                    raise
+                # an error of a pass that ran on UNVERIFIED packs is not the caller's: the checked path decides
         return self._forward_pass(hr, clamp, defer=False)
 
     def _forward_pass(self, hr, clamp, defer):
@@ -1060,7 +1085,7 @@ class HCFlowNet_Rescaling(_EngineModule):
         self._run_checked(eng, idx, lambda e_, lo, hi, stream: e_.lib.hcf_forward_rescale(
             e_.handle, hr[lo:hi].data_ptr(), out_lr[lo:hi].data_ptr(), z1[lo:hi].data_ptr(), z2[lo:hi].data_ptr(), hi - lo, H, W,
             fl, stream), "hcf_forward_rescale", batch=B, parts=self._parts(dev, idx, eng, B, allow=not pend),
-            threaded=_split_threaded(H * W))
+            threaded=_split_threaded())
         self._finish_actnorm_init(eng, idx, pend)
         return out_lr, z1, z2
 

@@ -1506,10 +1506,11 @@ struct hcf_engine {
     if (ovf_latch() != HCF_OK) return rc;
     if (ovf_sticky) {
       if (overflowed) *overflowed = 1;
-      if (sample_slots) *sample_slots = ovf_slots ? ovf_slots : 0x3fffffffu;
+      if (sample_slots) *sample_slots = (ovf_unattributed || !ovf_slots) ? 0x3fffffffu : ovf_slots;
       n_fallbacks++;
       ovf_sticky = false;
       ovf_slots = 0;
+      ovf_unattributed = false;
     }
     return HCF_OK;
   }
@@ -1523,13 +1524,17 @@ struct hcf_engine {
     ovf_pending = false;
     if (*ovf_host) {
       ovf_sticky = true;
-      ovf_slots |= ((uint32_t)*ovf_host >> 1) & 0x3fffffffu;     // bit 1 + (sample mod 30) of the device flag (hcf_conv_f16x3.hip)
+      const uint32_t v_ = (uint32_t)*ovf_host, slots_ = (v_ >> 1) & 0x3fffffffu;
+      ovf_slots |= slots_;                                         // bit 1 + (sample mod 30) of the device flag (hcf_conv_f16x3.hip)
+      // "all samples": bit 31 = a writer that could not name its sample (reserved for it: none of today's four writers needs it), or a
+      // read-back with bit 0 alone. Latched separately, so that slots named by ANOTHER kernel or pass cannot mask it.
+      if ((v_ & 0x80000000u) || slots_ == 0) ovf_unattributed = true;
       *ovf_host = 0;
       ovf_clear = true;
     }
     return HCF_OK;
   }
-  bool ovf_sticky = false, ovf_clear = false;
+  bool ovf_sticky = false, ovf_clear = false, ovf_unattributed = false;
   uint32_t ovf_slots = 0;
   uint32_t pass_flags = 0;
 };

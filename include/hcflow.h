@@ -153,7 +153,8 @@ int hcf_check_range(hcf_engine* e, int32_t* overflowed);
 /* The same check with the affected SAMPLES: every op of the path is per-sample (HCFlowNet_SR_arch.py:70-75, thops.sum(dim=[1,2,3])),
  * so an out-of-range activation invalidates only the samples whose tiles saw it. *sample_slots: bit (b mod 30) is set for every
  * sample index b (within its call's batch) that was flagged since the last check -- a superset for B > 30 (slots alias); all 30
- * bits when a flagging kernel could not name its sample. The caller re-runs only those samples with HCF_PRECISION_EXACT
+ * bits when a flagging kernel could not name its sample (device flag: bit 0 = overflow, bits 1..30 = sample slots, bit 31 =
+ * "unattributed", latched on its own so that slots named by another kernel or pass cannot mask it). The caller re-runs only those samples with HCF_PRECISION_EXACT
  * (hcflow_amd/arch.py: one B = 1 pass per flagged sample through hcf_inverse_ex with its sample offset) instead of the whole
  * batch. Reports and clears like hcf_check_range (one fallback counted). */
 int hcf_check_range_samples(hcf_engine* e, int32_t* overflowed, uint32_t* sample_slots);
