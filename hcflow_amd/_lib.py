@@ -29,7 +29,7 @@ SYMBOLS = [
     "hcf_op_gauss_sample", "hcf_bench_conv", "hcf_set_precision", "hcf_get_precision", "hcf_fallback_count",
     "hcf_op_set_precision", "hcf_debug_set_ablation", "hcf_debug_last_clock_mhz", "hcf_debug_clock_probe",
     "hcf_actnorm_init_request", "hcf_get_param", "hcf_op_conv2d_backward",
-    "hcf_train_forward_sr", "hcf_train_backward", "hcf_bind_param_device", "hcf_refresh_from_device",
+    "hcf_train_forward_sr", "hcf_train_backward", "hcf_train_backward_phase", "hcf_bind_param_device", "hcf_refresh_from_device",
     "hcf_train_inverse", "hcf_train_backward_inverse", "hcf_metric_psnr_ssim", "hcf_metric_imresize_down",
     "hcf_train_select_tape", "hcf_train_forward_rescale", "hcf_train_backward_rescale",
     "hcf_debug_range_probe", "hcf_debug_range_probe_read",
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     lib.hcf_refresh_from_device.argtypes = [vp, vp]
     lib.hcf_train_forward_sr.argtypes = [vp, fp, fp, fp, fp, fp, fp, i32, i32, i32, vp]
     lib.hcf_train_backward.argtypes = [vp, f32, fp, i64, vp]
+    lib.hcf_train_backward_phase.argtypes = [vp, i32, f32, fp, i64, vp]
     lib.hcf_actnorm_init_request.argtypes = [vp, C.POINTER(C.c_char_p), i32]
     lib.hcf_get_param.argtypes = [vp, C.c_char_p, fp, i64]
     lib.hcf_op_conv2d.argtypes = [C.POINTER(fp), C.POINTER(i32), C.POINTER(i32), i32, i32, i32, i32, fp, fp, fp,

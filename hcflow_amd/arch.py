@@ -291,6 +291,103 @@ class _SRNLLStep(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+# ---- the same step as TWO autograd nodes (gradient all-reduce overlapped with the backward pass) -----------------------------
+# The reference trains under DistributedDataParallel (HCFlow_SR_model.py:33-36): DDP reduces a bucket of gradients as soon as its
+# parameters' AccumulateGrad hooks have fired, under the rest of the backward pass. One autograd node for the whole net hands over
+# every gradient at once, after the last kernel. Two nodes: the OUTER one owns the parameters whose gradients are final after the first
+# phase of the engine's backward pass (hcf_train_backward_phase: the level-0 conditional flow, about half of an SR x4 net), the
+# INNER one the rest; autograd runs outer.backward (phase 0: its gradients go to DDP, whose all-reduce starts on its own stream), then
+# inner.backward (phase 1). `state` is any object with forward() -> tuple of outputs, backward(phase, grad_outputs) -> list of gradients
+# (phase 0: of `early`, phase 1: of `late`): the engine-backed one below, a plain-torch one in tests/test_dist_cpu.py.
+class _LateNode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, *late):
+        ctx.state = state
+        return torch.zeros((), device=late[0].device if late else None)
+
+    @staticmethod
+    def backward(ctx, g_token):
+        return (None,) + tuple(ctx.state.backward(1, None))
+
+
+class _EarlyNode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state, token, *early):
+        ctx.state = state
+        outs = state.forward()
+        ctx.mark_non_differentiable(*[o for o, d in zip(outs, state.differentiable) if not d])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        grads = ctx.state.backward(0, g_outs)
+        return (None, torch.zeros(()).to(g_outs[0].device if g_outs[0] is not None else "cpu")) + tuple(grads)
+
+
+def two_phase_apply(state, early, late):
+    """outputs of ``state.forward()`` on an autograd graph of two nodes (see above); ``early`` / ``late``: the parameter tensors whose
+    gradients ``state.backward(0, ...)`` / ``state.backward(1, ...)`` return."""
+    token = _LateNode.apply(state, *late)
+    return _EarlyNode.apply(state, token, *early)
+
+
+class _SRNLLTwoPhase:
+    """Engine-backed state of two_phase_apply for the NLL step: hcf_train_forward_sr, then hcf_train_backward_phase 0 / 1 into ONE
+    flat gradient buffer handed out as views."""
+    differentiable = (False, True, False)
+
+    def __init__(self, module, hr, lr, noise, params, early_idx):
+        self.module, self.hr, self.lr, self.noise = module, hr, lr, noise
+        self.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
+        self.early_idx = set(early_idx)
+        self.flat = None
+
+    def forward(self):
+        m, hr = self.module, self.hr
+        dev = hr.device
+        self.eng, self.idx = m._engine_for(dev)
+        B, _, H, W = hr.shape
+        s = m.cfg.scale
+        out_lr = torch.empty(B, 3, H // s, W // s, device=dev)
+        nll = torch.empty(1, device=dev)
+        logdet = torch.empty(B, device=dev)
+        eng = self.eng
+        with torch.cuda.device(self.idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
+            rc = eng.lib.hcf_train_forward_sr(eng.handle, hr.data_ptr(), self.lr.data_ptr(), self.noise.data_ptr(),
+                                              out_lr.data_ptr(), nll.data_ptr(), logdet.data_ptr(), B, H, W, m._stream(self.idx))
+        _lib.check(rc, eng.handle, "hcf_train_forward_sr")
+        return out_lr, nll.view(()), logdet
+
+    def backward(self, phase, g_outs):
+        eng, idx = self.eng, self.idx
+        total = sum(n for _, n, _ in self.meta)
+        if phase == 0:
+            self.flat = torch.empty(total, device=self.hr.device, dtype=torch.float32)
+            self.g_nll = float(g_outs[1])
+        with torch.cuda.device(idx):
+            _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
+            rc = eng.lib.hcf_train_backward_phase(eng.handle, phase, self.g_nll, self.flat.data_ptr(), total,
+                                                  C.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+        _lib.check(rc, eng.handle, "hcf_train_backward_phase")
+        grads, off = [], 0
+        for i, (shape, n, need) in enumerate(self.meta):
+            if (i in self.early_idx) == (phase == 0):
+                grads.append(self.flat[off:off + n].view(shape) if need else None)
+            off += n
+        return grads
+
+
+def _grad_nodes() -> int:
+    """Autograd nodes of the NLL step: HCFLOW_GRAD_NODES=1 / 2, default 2 under a process group of more than one rank (DDP overlap),
+    1 otherwise (the mid-pass flush of the two-phase backward costs a join of the weight-gradient stream and buys nothing alone)."""
+    v = os.environ.get("HCFLOW_GRAD_NODES")
+    if v in ("1", "2"):
+        return int(v)
+    import torch.distributed as dist
+    return 2 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
+
+
 class _SRReverseStep(torch.autograd.Function):
     """``fake_H = netG(lr=, eps_std=, reverse=True)`` with gradients w.r.t. the parameters (the HR pixel / feature /
     GAN losses of the HCFlow+ / ++ recipes, HCFlow_SR_model.py:207-255): hcf_train_inverse keeps the tape,
@@ -1020,6 +1117,14 @@ class HCFlowNet_SR(_EngineModule):
             # that with one statistics pass on the same batch / noise, then run the differentiable pass
             with torch.no_grad():
                 self.normal_flow_diracLR(hr, lr, noise=noise)
+        if _grad_nodes() == 2:
+            params = self._params()
+            early_idx = [i for i, k in enumerate(self._spec_keys) if k.startswith("flow.level0_condFlow.")]
+            if early_idx and len(early_idx) < len(params):
+                eset = set(early_idx)
+                st = _SRNLLTwoPhase(self, hr, lr, noise, params, early_idx)
+                out_lr, nll, _ = two_phase_apply(st, [params[i] for i in early_idx], [p for i, p in enumerate(params) if i not in eset])
+                return out_lr, nll
         out_lr, nll, _ = _SRNLLStep.apply(self, hr, lr, noise, *self._params())
         return out_lr, nll
 

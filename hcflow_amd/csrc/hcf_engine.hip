@@ -1753,6 +1753,12 @@ int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t nu
   return e->run_backward(in, dparams, (size_t)numel, (hipStream_t)stream);
 }
 
+int hcf_train_backward_phase(hcf_engine* e, int32_t phase, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream) {
+  if (!e || numel < 0 || phase < 0 || phase > 1) return HCF_ERR_ARG;
+  hcf_engine::BwdIn in = {1, grad_nll, nullptr, nullptr, nullptr, nullptr};
+  return e->run_backward(in, dparams, (size_t)numel, (hipStream_t)stream, phase);
+}
+
 int hcf_train_select_tape(hcf_engine* e, int32_t slot) {
   if (!e || slot < 0 || slot > 1) return HCF_ERR_ARG;
   e->cur_slot = slot;

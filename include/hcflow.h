@@ -184,6 +184,13 @@ size_t hcf_weight_bytes(const hcf_engine* e);
 int hcf_train_forward_sr(hcf_engine* e, const float* hr, const float* lr, const float* noise, float* out_lr,
                          float* out_nll, float* out_logdet, int32_t B, int32_t H, int32_t W, hcf_stream_t stream);
 int hcf_train_backward(hcf_engine* e, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
+/* The same backward pass in two calls, for a caller whose gradient all-reduce overlaps the backward pass (the reference trains under
+ * DistributedDataParallel, HCFlow_SR_model.py:33-36, whose buckets are reduced as their gradients arrive). phase 0 runs the part
+ * of the pass that was taped last -- the output terms and the level-0 conditional flow -- and completes every parameter-gradient
+ * reduction it enqueued on `stream`: when it returns (stream order), the slices of `dparams` of all parameters whose key starts with
+ * "flow.level0_condFlow." (about half of an SR x4 net) are FINAL and nothing later touches them. phase 1 (same `dparams`) runs the
+ * rest. The two calls together write exactly what hcf_train_backward writes, bit for bit. */
+int hcf_train_backward_phase(hcf_engine* e, int32_t phase, float grad_nll, float* dparams, int64_t numel, hcf_stream_t stream);
 
 /* Gradients through the REVERSE (sampling) path (reference: the HR pixel / feature / GAN losses of the HCFlow+ / ++
  * recipes, HCFlow_SR_model.py:207-255: `fake_H = netG(lr=, eps_std=, reverse=True)` followed by a loss on fake_H and

@@ -272,3 +272,104 @@ def test_wrap_ddp_without_a_process_group_is_the_module():
     net = _StubSR()
     assert wrap_ddp(net, torch.device("cpu")) is net
     assert grad_allreduce_bytes(net) == 4 * sum(p.numel() for p in net.parameters() if p.requires_grad)
+
+
+# ---------------------------------------------------------------- two autograd nodes: gradient all-reduce under the backward pass
+class _TwoPhaseStub(torch.nn.Module):
+    """A net whose training step goes through hcflow_amd.arch.two_phase_apply with a plain-torch state: `early` parameters get
+    their gradients in phase 0, `late` ones in phase 1 -- the structure of the engine-backed NLL step (arch._SRNLLTwoPhase)."""
+    def __init__(self, events):
+        super().__init__()
+        self.late = torch.nn.Linear(8, 8)               # registered first, as flow.layers.* is in the real net
+        self.early = torch.nn.Linear(8, 8)
+        self.events = events
+
+    def forward(self, x):
+        from hcflow_amd.arch import two_phase_apply
+        net, ev = self, self.events
+
+        class State:
+            differentiable = (True,)
+
+            def forward(self):
+                with torch.enable_grad():
+                    self.e = [p.detach().requires_grad_(True) for p in net.early.parameters()]
+                    self.l = [p.detach().requires_grad_(True) for p in net.late.parameters()]
+                    hmid = torch.tanh(torch.nn.functional.linear(x, self.l[0], self.l[1]))
+                    self.loss = (torch.nn.functional.linear(hmid, self.e[0], self.e[1]) ** 2).mean()
+                return (self.loss.detach(),)
+
+            def backward(self, phase, g):
+                if phase == 0:
+                    self.g = g[0]
+                    out = torch.autograd.grad(self.loss, self.e, self.g, retain_graph=True)
+                    ev.append("phase0_done")
+                    return list(out)
+                ev.append("phase1_start")
+                return list(torch.autograd.grad(self.loss, self.l, self.g))
+        (loss,) = two_phase_apply(State(), list(self.early.parameters()), list(self.late.parameters()))
+        return loss
+
+
+def _two_phase_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel
+        events = []
+        torch.manual_seed(0)
+        net = _TwoPhaseStub(events)
+        ref = _TwoPhaseStub([])
+        ref.load_state_dict(net.state_dict())
+        ddp = DistributedDataParallel(net, bucket_cap_mb=1e-4)          # every parameter its own bucket
+
+        def hook(state, bucket):
+            last_iter = len(events) - 1 - events[::-1].index("iter")
+            events.append(("bucket", bucket.index(), "phase1_start" in events[last_iter:]))
+            fut = dist.all_reduce(bucket.buffer(), async_op=True).get_future()
+            return fut.then(lambda f: f.value()[0] / world)
+        ddp.register_comm_hook(None, hook)
+        g = torch.Generator().manual_seed(50 + rank)
+        x = torch.rand(4, 8, generator=g)
+        overlapped = []
+        for it in range(3):
+            events.append("iter")
+            for p in net.parameters():
+                p.grad = None
+            ddp(x).backward()
+            cur = events[len(events) - 1 - events[::-1].index("iter"):]
+            early_before = [e for e in cur if isinstance(e, tuple) and not e[2]]
+            overlapped.append(len(early_before))
+        # gradients = the plain autograd gradients of the same loss, averaged over the ranks
+        xs = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(xs, x)
+        want = [torch.zeros_like(p) for p in ref.parameters()]
+        for xr in xs:
+            hmid = torch.tanh(ref.late(xr))
+            gr = torch.autograd.grad((ref.early(hmid) ** 2).mean(), list(ref.parameters()))
+            want = [w + g_ / world for w, g_ in zip(want, gr)]
+        ok = all(torch.allclose(p.grad, w, atol=1e-6) for p, w in zip(net.parameters(), want))
+        q.put((rank, bool(ok), overlapped))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_autograd_nodes_let_ddp_reduce_the_first_buckets_before_the_backward_pass_ends_gloo_world2():
+    """HCFlow_SR_model.py:33-36 wraps netG in DistributedDataParallel, whose bucketed all-reduce overlaps the backward pass. With the
+    NLL step as two autograd nodes (hcflow_amd.arch.two_phase_apply; engine: hcf_train_backward_phase) the buckets of the `early`
+    parameters are handed to the communication hook BEFORE phase 1 starts -- from the second iteration on (DDP rebuilds its buckets
+    in gradient-arrival order after the first) -- and the reduced gradients are the plain autograd ones."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_phase_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p_ in procs:
+        p_.join(60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)]
+    for _, _, overlapped in res:
+        assert overlapped[1] >= 1 and overlapped[2] >= 1, overlapped      # buckets launched before phase 1, iterations 2 and 3

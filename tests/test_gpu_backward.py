@@ -778,3 +778,65 @@ def test_training_steps_between_split_inference_calls_keep_their_gradients():
         for a, b in zip(g0, g1):
             assert np.array_equal(a, b)
     assert all(torch.equal(samples[0], s) for s in samples[1:])
+
+
+def test_two_phase_backward_equals_the_single_call_and_finishes_the_early_group_first():
+    """hcf_train_backward_phase (DDP overlap): phase 0 + phase 1 write bit for bit what hcf_train_backward writes; after phase 0
+    the slices of the parameters under flow.level0_condFlow. are already final (phase 1 does not touch them) and the rest is not;
+    through the module, HCFLOW_GRAD_NODES=2 (two autograd nodes) gives the gradients of the one-node step."""
+    import ctypes as C
+    import os
+    from hcflow_amd import _lib
+    cfg, net = _fresh_sr("SR_4X_tiny", 11)
+    net.train()
+    g = torch.Generator().manual_seed(29)
+    hr = torch.rand(2, 3, 64, 96, generator=g).cuda()
+    lr = torch.rand(2, 3, 16, 24, generator=g).cuda()
+    noise = torch.rand(hr.shape, generator=g).cuda()
+
+    def step(nodes):
+        os.environ["HCFLOW_GRAD_NODES"] = str(nodes)
+        try:
+            for p in net.parameters():
+                p.grad = None
+            _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+            nll.backward()
+            return float(nll.detach()), [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        finally:
+            os.environ.pop("HCFLOW_GRAD_NODES", None)
+    n1, g1 = step(1)
+    n2, g2 = step(2)
+    assert n1 == n2
+    assert all((a is None) == (b is None) for a, b in zip(g1, g2))
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2) if a is not None)
+    # the C ABI directly: early slices final after phase 0
+    eng = net.engine()
+    lib, h = eng.lib, eng.handle
+    keys = list(net._spec_keys)
+    sizes = [p.numel() for p in net._params()]
+    total = sum(sizes)
+    flat = torch.zeros(total, device="cuda")
+    out_lr = torch.empty(2, 3, 16, 24, device="cuda"); nll = torch.empty(1, device="cuda"); ld = torch.empty(2, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.hcf_train_forward_sr(h, hr.data_ptr(), lr.data_ptr(), noise.data_ptr(), out_lr.data_ptr(), nll.data_ptr(),
+                                        ld.data_ptr(), 2, 64, 96, st), h, "fwd")
+    _lib.check(lib.hcf_train_backward_phase(h, 0, 1.0, flat.data_ptr(), total, st), h, "phase 0")
+    mid = flat.clone()
+    assert lib.hcf_train_backward(h, 1.0, flat.data_ptr(), total, st) != 0          # phase 1 is pending: anything else is refused
+    _lib.check(lib.hcf_train_backward_phase(h, 1, 1.0, flat.data_ptr(), total, st), h, "phase 1")
+    off, early_n, late_changed = 0, 0, False
+    for k, n in zip(keys, sizes):
+        a, b = mid[off:off + n], flat[off:off + n]
+        if k.startswith("flow.level0_condFlow."):
+            assert torch.equal(a, b), k
+            early_n += n
+        else:
+            late_changed = late_changed or not torch.equal(a, b)
+        off += n
+    assert 0 < early_n < total and late_changed
+    _lib.check(lib.hcf_train_forward_sr(h, hr.data_ptr(), lr.data_ptr(), noise.data_ptr(), out_lr.data_ptr(), nll.data_ptr(),
+                                        ld.data_ptr(), 2, 64, 96, st), h, "fwd")
+    one = torch.zeros(total, device="cuda")
+    _lib.check(lib.hcf_train_backward(h, 1.0, one.data_ptr(), total, st), h, "backward")
+    assert torch.equal(one, flat)
+    assert lib.hcf_train_backward_phase(h, 1, 1.0, one.data_ptr(), total, st) != 0    # no phase 0 before it
