@@ -379,13 +379,12 @@ class _SRNLLTwoPhase:
 
 
 def _grad_nodes() -> int:
-    """Autograd nodes of the NLL step: HCFLOW_GRAD_NODES=1 / 2, default 2 under a process group of more than one rank (DDP overlap),
-    1 otherwise (the mid-pass flush of the two-phase backward costs a join of the weight-gradient stream and buys nothing alone)."""
-    v = os.environ.get("HCFLOW_GRAD_NODES")
-    if v in ("1", "2"):
-        return int(v)
-    import torch.distributed as dist
-    return 2 if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else 1
+    """Autograd nodes of the NLL step: 1 (default) or 2 (HCFLOW_GRAD_NODES=2). Measured on one MI355X (config 5, B = 16,
+    profiles/r06_notes.md): the two-phase backward costs 6-9 ms of a 57.7 ms step -- its mid-pass flush joins the low-priority
+    weight-gradient stream, which runs ~10 ms behind the data-gradient chain and otherwise catches up in the chain's gaps -- while
+    the all-reduce it hides is 92.9 MB, ~2-3 ms on xGMI. It pays only where the gradient all-reduce is slower than that (PCIe or
+    network-attached ranks); over xGMI the one-node step with the all-reduce behind the last kernel is the faster one."""
+    return 2 if os.environ.get("HCFLOW_GRAD_NODES") == "2" else 1
 
 
 class _SRReverseStep(torch.autograd.Function):
