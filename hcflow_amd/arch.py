@@ -56,7 +56,7 @@ class InvertibleConv1x1(nn.Module):
     """Parameter holder of Permutations.InvertibleConv1x1 (Permutations.py:33-58): random orthogonal init; with
     ``LU_decomposed`` the factors of W = P (L o l_mask + I) (U o l_mask^T + diag(sign_s exp(log_s))) -- parameters l, log_s, u,
     buffers p, sign_s (fixed), plain attributes l_mask, eye -- under the reference's names. The engine composes W / W^-1 and
-    uses dlogdet = sum(log_s) * pixels (Permutations.py:78-92; hcf_engine.hip build_step)."""
+    uses dlogdet = sum(log_s) * pixels (Permutations.py:78-92; hcf_engine_build.inc build_step)."""
 
     def __init__(self, num_channels, LU_decomposed=False):
         super().__init__()

@@ -125,7 +125,7 @@ def test_rescaling_roundtrip_full_size_vs_cpu_oracle():
 
 def test_config2_b16_timed_configuration_vs_cpu_oracle():
     """The configuration bench.py TIMES (BASELINE config 2: full depth, B = 16, LR 160x160, tau 0.8, module default f16x3):
-    kernel routing depends on the batch (hcf_engine.hip run_rdb: conv_wino_rounds_ok(B, H, W, ...) gates the fat launches), so the
+    kernel routing depends on the batch (hcf_engine_run.inc run_rdb: conv_wino_rounds_ok(B, H, W, ...) gates the fat launches), so the
     B = 1 / 2 oracle comparisons above do not cover the schedule of the timed pass. Every op is per-sample
     (HCFlowNet_SR_arch.py:70-75, thops.sum(dim=[1,2,3])), so samples {0, 7, 15} of ONE B = 16 engine call are compared with
     three B = 1 oracle passes on the same LR / eps slices."""
