@@ -291,76 +291,6 @@ class _SRNLLStep(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
-class _SRNLLStepSplit(torch.autograd.Function):
-    """_SRNLLStep as TWO half batches on two engines (HCFLOW_TRAIN_SPLIT=1, experiment): at the training patch size (LR 40 x 40) most
-    launches of the pass fill a third of the CUs for one round, so the two halves' dependency chains run side by side -- half 0 on the
-    caller's stream, half 1 on a stream of the module's own, the second enqueued by the helper thread. nll = the sample-weighted mean
-    of the halves' (the objective is a mean over samples, HCFlow_SR_model.py:195-199), d nll / d parameters = the sum of the
-    halves' flat gradients (each scaled by its share of the batch inside the engine)."""
-
-    @staticmethod
-    def forward(ctx, module, hr, lr, noise, *params):
-        dev = hr.device
-        eng0, idx = module._engine_for(dev)
-        eng1, _ = module._engine_for(dev, slot=1, same_call=True)
-        B, _, H, W = hr.shape
-        s = module.cfg.scale
-        h1 = B - B // 2
-        out_lr = torch.empty(B, 3, H // s, W // s, device=dev)
-        nll2 = torch.empty(2, device=dev)
-        logdet = torch.empty(B, device=dev)
-        with torch.cuda.device(idx):
-            cur = torch.cuda.current_stream(idx)
-            side = module._train_split_stream(idx)
-            side.wait_stream(cur)
-
-            def run(eng, lo, hi, slot, stream):
-                _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
-                return eng.lib.hcf_train_forward_sr(eng.handle, hr[lo:hi].data_ptr(), lr[lo:hi].data_ptr(), noise[lo:hi].data_ptr(),
-                                                    out_lr[lo:hi].data_ptr(), nll2[slot:slot + 1].data_ptr(), logdet[lo:hi].data_ptr(),
-                                                    hi - lo, H, W, C.c_void_p(stream.cuda_stream))
-            fut = _enqueue_pool().submit(run, eng1, h1, B, 1, side)
-            rc0 = run(eng0, 0, h1, 0, cur)
-            rc1 = fut.result()
-            _lib.check(rc0, eng0.handle, "hcf_train_forward_sr")
-            _lib.check(rc1, eng1.handle, "hcf_train_forward_sr")
-            cur.wait_stream(side)
-            nll = (nll2[0] * (h1 / B) + nll2[1] * ((B - h1) / B)).view(())
-        ctx.engs, ctx.idx, ctx.h1, ctx.B, ctx.side = (eng0, eng1), idx, h1, B, side
-        ctx.keep = (hr, lr, noise)
-        ctx.meta = [(tuple(p.shape), p.numel(), bool(p.requires_grad)) for p in params]
-        ctx.mark_non_differentiable(out_lr, logdet)
-        return out_lr, nll, logdet
-
-    @staticmethod
-    def backward(ctx, g_lr, g_nll, g_logdet):
-        (eng0, eng1), idx, h1, B, side = ctx.engs, ctx.idx, ctx.h1, ctx.B, ctx.side
-        total = sum(n for _, n, _ in ctx.meta)
-        dev = ctx.keep[0].device
-        flat = torch.empty(total, device=dev, dtype=torch.float32)
-        flat1 = torch.empty(total, device=dev, dtype=torch.float32)
-        g = float(g_nll)
-        with torch.cuda.device(idx):
-            cur = torch.cuda.current_stream(idx)
-            side.wait_stream(cur)
-
-            def run(eng, share, buf, stream):
-                _lib.check(eng.lib.hcf_train_select_tape(eng.handle, 0), eng.handle, "hcf_train_select_tape")
-                return eng.lib.hcf_train_backward(eng.handle, g * share, buf.data_ptr(), total, C.c_void_p(stream.cuda_stream))
-            fut = _enqueue_pool().submit(run, eng1, (B - h1) / B, flat1, side)
-            rc0 = run(eng0, h1 / B, flat, cur)
-            rc1 = fut.result()
-            _lib.check(rc0, eng0.handle, "hcf_train_backward")
-            _lib.check(rc1, eng1.handle, "hcf_train_backward")
-            cur.wait_stream(side)
-            flat.add_(flat1)
-        grads, off = [], 0
-        for shape, n, need in ctx.meta:
-            grads.append(flat[off:off + n].view(shape) if need else None)
-            off += n
-        return (None, None, None, None) + tuple(grads)
-
-
 # ---- the same step as TWO autograd nodes (gradient all-reduce overlapped with the backward pass) -----------------------------
 # The reference trains under DistributedDataParallel (HCFlow_SR_model.py:33-36): DDP reduces a bucket of gradients as soon as its
 # parameters' AccumulateGrad hooks have fired, under the rest of the backward pass. One autograd node for the whole net hands over
@@ -645,13 +575,6 @@ class _EngineModule(nn.Module):
                 raise _lib.HcfError("hcf_aux_stream(%d, %d) failed (%d)" % (dev, slot, rc))
             st = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", dev))
             self._side_streams[idx] = st
-        return st
-
-    def _train_split_stream(self, idx):
-        st = self.__dict__.get("_tsplit_streams", {}).get(idx)
-        if st is None:
-            st = torch.cuda.Stream(device=idx)
-            self.__dict__.setdefault("_tsplit_streams", {})[idx] = st
         return st
 
     def engines(self):
@@ -1201,9 +1124,6 @@ class HCFlowNet_SR(_EngineModule):
                 st = _SRNLLTwoPhase(self, hr, lr, noise, params, early_idx)
                 out_lr, nll, _ = two_phase_apply(st, [params[i] for i in early_idx], [p for i, p in enumerate(params) if i not in eset])
                 return out_lr, nll
-        if os.environ.get("HCFLOW_TRAIN_SPLIT") == "1" and hr.shape[0] >= 4 and not _capturing():
-            out_lr, nll, _ = _SRNLLStepSplit.apply(self, hr, lr, noise, *self._params())
-            return out_lr, nll
         out_lr, nll, _ = _SRNLLStep.apply(self, hr, lr, noise, *self._params())
         return out_lr, nll
 
