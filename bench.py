@@ -847,6 +847,7 @@ def cpu_baseline(cfg, params, h, passes):
             if best is None or t < best:
                 best, threads = t, c
         torch.set_num_threads(threads)
+        fn(lr, params, cfg, 0.0)                           # settle: the first pass after the all-cores calibration pass runs 20-30 % slow
         for _ in range(passes):
             t0 = time.perf_counter()
             out = fn(lr, params, cfg, 0.0)
