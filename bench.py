@@ -647,8 +647,12 @@ def train_workload(args, dev, world, rank):
                        "optimizer": names[args.optim == "native"]},
             "detail": first,
             "other_optimizer": dict(second, optimizer=names[args.optim != "native"]),
-            "roofline": {"bound": "mfma", "achieved": round(first["mfma_frac"] * peak, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": first["mfma_frac"], "traffic": None, "power": power.get(args.optim == "native"),
+            # as the sampling line: `peak` = the guide's dense peak of the matrix pipe the mode uses (f16x3: 2 500, of which three
+            # MFMAs go into one fp32-equivalent product block -> `frac_of_split_yardstick` against 2 500 / 3; exact: 157.3)
+            "roofline": {"bound": "mfma", "achieved": round(first["mfma_frac"] * peak, 2),
+                         "peak": PEAK_F32_MFMA_TFLOPS if args.precision == "exact" else PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(first["mfma_frac"] * peak / (PEAK_F32_MFMA_TFLOPS if args.precision == "exact" else PEAK_F16_MFMA_TFLOPS), 4),
+                         "frac_of_split_yardstick": first["mfma_frac"], "traffic": None, "power": power.get(args.optim == "native"),
                          "note": "whole step: algorithmic FLOPs (forward 184.27 GFLOP per sample x ~3 with the backward pass, BASELINE.md "
                                  "section 2) / step time, per GPU; per-kernel tables of this step: profiles/rNN_kernel_stats_train_step_*"},
             "cpu_baseline": None,
