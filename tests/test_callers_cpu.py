@@ -56,3 +56,19 @@ def test_optimizer_parameter_groups_follow_our_named_parameters(tag):
     assert len(want) == len(param_spec(cfg)) - sum(1 for k, _, kind in param_spec(cfg) if kind == "haar")
     lr, b1, b2, wd, eps = [float(v) for v in g[tag + "_optim_hyper"]]
     assert (lr, b1, b2, wd, eps) == (2.5e-4, 0.9, 0.99, 0.0, 1e-8)
+
+
+@pytest.mark.parametrize("tag,name", [("test_sr4", "SR_DF2K_4X"), ("test_sr8", "SR_CelebA_8X"), ("test_rescale", "Rescaling_DF2K_4X")])
+def test_presets_equal_the_reference_yml_network_blocks(tag, name):
+    """The three presets (what bench.py, the fixtures and the oracle's eps shapes are built from) against the reference's OWN parse of
+    its shipped yml files: run_reference_callers.py recorded NetConfig.from_opt(options.parse(codes/options/test/test_*.yml)) in the
+    build container. A typo in a preset -- K, the split positions, RRDB_nb, the widths -- would be shared by product and oracle and
+    invisible to every GPU parity test (parity footnote a); here it is not."""
+    from hcflow_amd.config import preset, eps_shapes, param_spec
+    g = load_golden("callers_test")
+    ref = caller_cfg(g, tag)
+    ours = preset(name)
+    assert repr(ref) == repr(ours)
+    assert ref.to_opt() == ours.to_opt()
+    assert [k for k, _, _ in param_spec(ref)] == [k for k, _, _ in param_spec(ours)]
+    assert eps_shapes(ref, 2, 16, 24) == eps_shapes(ours, 2, 16, 24)
