@@ -33,6 +33,10 @@ def conv2d(x, w, b=None, stride=1, padding=0, *a, **k):
         xh = x.bfloat16().float(); xl = (x - xh).bfloat16().float()
         wh = w.bfloat16().float(); wl = (w - wh).bfloat16().float()
         y = _orig(xh, wh, None, stride, padding) + (_orig(xh, wl, None, stride, padding) + _orig(xl, wh, None, stride, padding))
+    elif MODE["m"] in ("f16x2_no_alo", "f16x2_no_wlo"):     # two of the three products (round 6: is the third one needed? yes: 6-8e-3)
+        xh = x.half().float(); xl = (x - xh).half().float()
+        wh, wl = split(w)
+        y = _orig(xh, wh, None, stride, padding) + (_orig(xh, wl, None, stride, padding) if MODE["m"] == "f16x2_no_alo" else _orig(xl, wh, None, stride, padding))
     elif MODE["m"] == "f16":
         y = _orig(x.half().float(), w.half().float(), None, stride, padding)
     if b is not None:
@@ -53,7 +57,7 @@ for name, h in (("SR_DF2K_4X", 24), ("SR_CelebA_8X", 10), ("Rescaling_DF2K_4X", 
         ref64 = inv(lr.double(), p64, cfg, 0.8, [e.double() for e in eps], clamp=False)
         ref32 = inv(lr, p, cfg, 0.8, eps, clamp=False)
         out = {}
-        for m in ("f16x3", "f16x3u", "bf16x3", "f16"):
+        for m in ("f16x3", "f16x3u", "bf16x3", "f16", "f16x2_no_alo", "f16x2_no_wlo"):
             MODE["m"] = m
             out[m] = inv(lr, p, cfg, 0.8, eps, clamp=False)
     sc = float(ref64.abs().max())
