@@ -114,6 +114,7 @@ size_t pack_conv_weights_1x1_frag(const float* w, std::vector<float>& out);
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st);
 int wino_clock_probe(int enable);            // hcf_conv_wino.hip: in-kernel clock probe of the 64-channel kernel
 double wino_clock_probe_mhz();
+int conv_wino_grid(int B, int H, int W, int ntile_n);           // blocks of such a launch (= rows of partial sums of its fused epilogue backward)
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n);     // false: launch_conv_wino would hand this launch to the direct kernel
 int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, void* pk, hipStream_t st);   // pack rebuilt from device weights
 // One Winograd pack rebuilt from device weights. Element (oc, ic) of the PACK comes from row oc of `w` (oc < split) or row oc - split
@@ -122,7 +123,11 @@ int launch_repack_wino(const float* w_dev, int cin, int cout, int cout_tile, voi
 // -> zero, else ic - z1_pad + z1_n. The derived packs of hcf_engine.hip (fat dense-block pairs, padded-z1 FCN / DenseBlock convs) are
 // all of this shape. frag1x1 != 0: the job is the lane-order pack of a 1x1 64 -> 64 layer instead (wino::pack_weights_1x1_frag).
 struct RepackWinoJob { const float* w; void* pk; int cin, cout, cout_tile; long long blk0;                             // blk0: first block of the job (ascending)
-                       const float* w2; int split, ld, ld2, z1_n, z1_pad, frag1x1; };
+                       const float* w2; int split, ld, ld2, z1_n, z1_pad, frag1x1;
+                       // tr != 0 (gather-form data-gradient packs of a dense block, hcf_engine_train.inc): the job rewrites input channels
+                       // [k0, k0 + kn) of a pack of `cin` input channels from ONE forward conv's weight, transposed and flipped:
+                       // L[n][k][t] = w[(k - k0) * ld + (tr_off + n) * 9 + (8 - t)], n < cout
+                       int tr, k0, kn, tr_off; };
 int launch_repack_wino_batch(const RepackWinoJob* jobs_dev, int njobs, long long nblocks, hipStream_t st);
 
 // ---- conv weight gradient (training path) ---------------------------------------------------------------------

@@ -72,6 +72,16 @@ struct Args {
   // LDS as the B operand of a 64 x 64 product: out = act_f((W_f h1 + f_bias) * f_scale); res1 / res2 / out2 are unused.
   const char* f_w;                                          // pack_weights_1x1_frag: 16 KB
   const float* f_bias; const float* f_scale; int f_act;
+  // Data-gradient form (training: hcf_engine_train.inc bwd_conv; the SC template variants): the input is a gradient tensor, multiplied
+  // by a power of two derived from *in_max (its max |x|, device) inside the f16 split -- gradients of 1e-8 would otherwise vanish
+  // in the f16 planes -- and the sums are scaled back in the epilogue (as hcf_conv_f16x3.hip's SCALED variants).
+  const float* in_max;
+  // 32-channel kernel, SC, no residuals: fused epilogue backward of the conv whose dL/dy this launch completes (ConvArgs::fb_y):
+  // y = that conv's forward output; stores dL/dpre = dL/dy * act'(y), leaves one row of per-channel sums per BLOCK in fb_part
+  // ([gridDim.x][2][cout]: row 0 = sum dL/dpre, row 1 = zeros) and the maxima |dL/dpre| in fb_max / max(that, *in_max) in fb_max2.
+  const float* fb_y; int fb_y_cs, fb_y_c0;
+  int fb_act;              // 0 none, 1 relu, 2 leaky relu 0.2 (of the conv whose output y is)
+  float* fb_part; float* fb_max; float* fb_max2;
   int* ovf;
   const char* zeros;       // >= 64 bytes of zeros
   int rev;                 // walk the units in reverse order (the engine alternates per launch: the consumer starts on what the producer touched last, which the 256 MB MALL still holds)
@@ -213,6 +223,8 @@ constexpr int A2_BYTES = 39 * 1024;               // 39 DMA instructions (48 dea
 constexpr int STAGE2 = A2_BYTES + W_BYTES;        // 72 704 = 71 instructions
 constexpr int TAB2_OFF = 2 * STAGE2;
 constexpr int LDS2_BYTES = TAB2_OFF + 512;        // 145 920
+constexpr int FB2_OFF = LDS2_BYTES;               // SC variants: per-thread channel-quad sums of the fused epilogue backward (8 KB) + the block's max
+constexpr int LDS2S_BYTES = FB2_OFF + 512 * 16 + 64;      // 154 176
 constexpr int ROWB = HWP * 64;                    // 2 176 bytes per halo row
 // byte offset of (halo row, column x, 16-byte part): rows are affine (row * ROWB), the swizzle depends on the column only, so a
 // lane needs ONE base register per patch column and reaches the patch rows through immediates / a scalar row offset
@@ -237,6 +249,35 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& h, u32x4& l) 
   }
 }
 
+// the same split of v * s, s a power of two (SC variants): hi = f16(v s) and lo = f16(v s - hi) by the mixed-precision FMA alone
+// (2 instructions per value instead of 1.5: the scaling is free)
+__device__ __forceinline__ void split8s(const float (&v)[8], const float s, u32x4& h, u32x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t hi, lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hi) : "v"(v[2 * i]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hi) : "v"(v[2 * i + 1]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(v[2 * i]), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v[2 * i + 1]), "v"(s), "v"(hi));
+    h[i] = hi;
+    l[i] = lo;
+  }
+}
+// x * in_s lands in [2^9, 2^10] at the tensor's max |x| (the transformed values reach 4x that: 2^12 << 65504)
+__device__ __forceinline__ void input_scales(const float* in_max, float& in_s, float& out_s, int& in_max_bits) {
+  in_s = 1.f; out_s = 1.f;
+  in_max_bits = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *in_max));
+  const float mx = __builtin_bit_cast(float, in_max_bits);
+  if (mx > 0.f && mx < 3.0e38f) {
+    int ex = 0;
+    (void)frexpf(mx, &ex);                       // mx = m * 2^ex, m in [0.5, 1)
+    in_s = ldexpf(1.f, 10 - ex);
+    out_s = ldexpf(1.f, ex - 10);
+  }
+  in_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, in_s)));
+  out_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, out_s)));
+}
+
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4& v, u32x2& h, u32x2& l) {
 #pragma unroll
@@ -250,7 +291,7 @@ __device__ __forceinline__ void split4(const f32x4& v, u32x2& h, u32x2& l) {
   }
 }
 
-template <int RES>
+template <int RES, bool SC = false>
 __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const int nunits) {
   using namespace v2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -356,10 +397,21 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
   const float sg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, xp ? -1.f : 1.f)));
   const int fw = A2_BYTES + half * 512 + li * 16 + xp * (8 * 4 * 512);   // + ((local pos * 2 + plane) * 2) * 512
 
+  float in_s = 1.f, out_s = 1.f;
+  int in_max_bits = 0;
+  if (SC) input_scales(a.in_max, in_s, out_s, in_max_bits);
+  constexpr bool FBK = SC && RES == 0;           // the fused epilogue backward exists in this variant
+  const bool fb = FBK && a.fb_y != nullptr;
   if (tid < 64) {
     const float sc_ = (tid < 32 * ntn) ? a.scale[tid] : 1.f, bi_ = (tid < 32 * ntn) ? a.bias[tid] : 0.f;
     reinterpret_cast<float*>(lds + TAB2_OFF)[tid] = bi_ * sc_;
-    reinterpret_cast<float*>(lds + TAB2_OFF)[64 + tid] = sc_ * UNSPLIT;
+    reinterpret_cast<float*>(lds + TAB2_OFF)[64 + tid] = sc_ * UNSPLIT * out_s;
+  }
+  if (FBK) {
+    if (fb) {
+      *reinterpret_cast<f32x4*>(lds + FB2_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tid == 0) *reinterpret_cast<int*>(lds + FB2_OFF + 512 * 16) = 0;
+    }
   }
   int u = blockIdx.x;
   if (u >= nunits) return;
@@ -422,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
     float v_[8];                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 8; ++k) v_[k] = W2_V(nu, T, k);                          \
     u32x4 vh_, vl_;                                                                                \
-    split8(v_, vh_, vl_);                                                                          \
+    if (SC) split8s(v_, in_s, vh_, vl_); else split8(v_, vh_, vl_);                                \
     const f16x8 w1_ = *reinterpret_cast<const f16x8*>(sb + fw + (((I) * 4 + nu) * 4) * 512);       \
     const f16x8 w2_ = *reinterpret_cast<const f16x8*>(sb + fw + (((I) * 4 + nu) * 4 + 2) * 512);   \
     W2_MFMA((I) * 4 + nu, w1_, vh_)                                                                \
@@ -474,6 +526,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
     const unsigned long long qe0 = __builtin_readcyclecounter();
 #endif
     float chk = 0.f;                               // Inf / NaN anywhere in the accumulators reaches a partial output
+    f32x4 fbs = {0.f, 0.f, 0.f, 0.f};              // fused epilogue backward: this unit's sums of the lane's channel quad, max |dL/dpre|
+    float fbm = 0.f;
+    const float fb_neg = a.fb_act == 1 ? 0.f : a.fb_act == 2 ? 0.2f : 1.f;
     {
       char* const xbuf = lds + ((g - 1) & 1) * STAGE2 + tg * 16384;
       const int p8 = lane >> 3, qd = (lane >> 1) & 3, hd = lane & 1;            // reader role
@@ -505,6 +560,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
             if (RES == 1 || RES == 2) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res1 + pixs[sgrp][ob] * a.res1_cs + a.res1_c0 + cb);
             if (RES == 2) rv2[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.res2 + pixs[sgrp][ob] * a.res2_cs + a.res2_c0 + cb);
             if (RES == 3) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.pre + pixs[sgrp][ob] * a.pre_cs + a.pre_c0 + cb);
+            if (FBK) { if (fb) rv1[sgrp][ob] = *reinterpret_cast<const f32x4*>(a.fb_y + pixs[sgrp][ob] * a.fb_y_cs + a.fb_y_c0 + cb); }
           }
         }
         if (oa == 1) __builtin_amdgcn_s_barrier(); // round 0's buffer has been read
@@ -546,6 +602,19 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
               if (RES == 1 || RES == 2) v[e] = fmaf(v[e], a.rs1, rv1[sgrp][ob][e]);
               if (RES == 2) v[e] = fmaf(v[e], a.rs2, rv2[sgrp][ob][e]);
             }
+            if (FBK) {
+              if (fb && oks[sgrp][ob] && cb < a.cout) {          // dL/dy -> dL/dpre of the conv that produced y (as conv_epilogue_bwd_kernel)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float yv = rv1[sgrp][ob][e];
+                  const bool pos = a.fb_act == 1 ? (yv > 0.f) : (yv >= 0.f);
+                  const float dz = (a.fb_act == 0 || pos) ? v[e] : v[e] * fb_neg;
+                  v[e] = dz;
+                  fbs[e] += dz;
+                  fbm = fmaxf(fbm, fabsf(dz));
+                }
+              }
+            }
             if (oks[sgrp][ob] && cb < a.cout) {
               if (second) *reinterpret_cast<f32x4*>(a.out2 + pixs[sgrp][ob] * a.out2_cs + a.out2_c0 + (cb - a.out2_split)) = v;
               else *reinterpret_cast<f32x4*>(a.out + pixs[sgrp][ob] * a.out_cs + a.out_c0 + cb) = v;
@@ -556,11 +625,39 @@ __global__ __launch_bounds__(512, 1) void conv_wino2_kernel(const Args a, const 
     if (__any(chk != chk)) {
       if (lane == 0) atomicOr(a.ovf, 1 | (2 << (eb % 30)));     // bit 0 + the unit's sample slot (see hcf_conv_f16x3.hip)
     }
+    if (FBK) {
+      if (fb) {                                    // own slot: no other thread touches it (a fixed summation order per block)
+        f32x4* const slot = reinterpret_cast<f32x4*>(lds + FB2_OFF + tid * 16);
+        *slot = *slot + fbs;
+        if (fbm > 0.f) atomicMax(reinterpret_cast<int*>(lds + FB2_OFF + 512 * 16), __builtin_bit_cast(int, fbm));
+      }
+    }
 #if defined(WINO_PROF)
     pw[3] += __builtin_readcyclecounter() - qe0;
 #endif
     u = un;
     if (u >= nunits) break;
+  }
+  if (FBK) {
+    if (fb) {
+      // the lane's channel quad is (lane & 7) in every unit: channel c = 4 (lane & 7) + e sums the 64 threads (8 waves x 8 patch
+      // groups) that hold it, in a fixed order; one row of partials per block (reduced later by launch_sum_jobs)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 32) {
+        const int q4 = tid >> 2, e = tid & 3;
+        float t0 = 0.f;
+        for (int j = 0; j < 64; ++j) t0 += reinterpret_cast<const float*>(lds + FB2_OFF)[(j * 8 + q4) * 4 + e];
+        if (tid < a.cout) {
+          a.fb_part[((size_t)blockIdx.x * 2 + 0) * a.cout + tid] = t0;
+          a.fb_part[((size_t)blockIdx.x * 2 + 1) * a.cout + tid] = 0.f;
+        }
+      }
+      if (tid == 0) {
+        const int m = *reinterpret_cast<const int*>(lds + FB2_OFF + 512 * 16), m2 = max(m, in_max_bits);
+        if (a.fb_max && m) atomicMax(reinterpret_cast<int*>(a.fb_max), m);
+        if (a.fb_max2 && m2) atomicMax(reinterpret_cast<int*>(a.fb_max2), m2);
+      }
+    }
   }
 #if defined(WINO_PROF)
   if (a.dbg && lane == 0 && (blockIdx.x & 31) == 17) {
@@ -762,7 +859,7 @@ __device__ __forceinline__ void wino64_epilogue(const Args& a, char* const lds, 
   }
 }
 
-template <int RES>
+template <int RES, bool SC = false>
 __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const int nunits) {
   using namespace v4;
   using v2::ROWB;
@@ -876,9 +973,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
   const int fw = lane * 16 + xi * (12 * 1024);   // + (nu * 3 + s) * 1024
 
   constexpr bool F1 = (RES == 3);                // fused 1x1 second layer (Args::f_w)
+  float in_s = 1.f, out_s = 1.f;
+  int in_max_bits = 0;
+  if (SC) input_scales(a.in_max, in_s, out_s, in_max_bits);
+  (void)in_max_bits;
   if (tid < 64) {
     reinterpret_cast<float*>(lds + TAB4_OFF)[tid] = a.bias[tid] * a.scale[tid];
-    reinterpret_cast<float*>(lds + TAB4_OFF)[64 + tid] = a.scale[tid] * UNSPLIT;
+    reinterpret_cast<float*>(lds + TAB4_OFF)[64 + tid] = a.scale[tid] * UNSPLIT * out_s;
     if (F1) {
       reinterpret_cast<float*>(lds + TAB4_OFF)[128 + tid] = a.f_bias[tid] * a.f_scale[tid];
       reinterpret_cast<float*>(lds + TAB4_OFF)[192 + tid] = a.f_scale[tid] * UNSPLIT;
@@ -979,7 +1080,7 @@ __global__ __launch_bounds__(512, 1) void conv_wino4_kernel(const Args a, const 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v_[k] = W4_V(nu, k);
         u32x4 vh_, vl_;
-        split8(v_, vh_, vl_);
+        if (SC) split8s(v_, in_s, vh_, vl_); else split8(v_, vh_, vl_);
         const f16x8 w00 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 0) * 1024);
         const f16x8 w01 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 1) * 1024);
         const f16x8 w10 = *reinterpret_cast<const f16x8*>(wb + (nu * 3 + 2) * 1024);
@@ -1057,25 +1158,33 @@ static inline int launch(const Args& a, int ncu, hipStream_t st, int version = 2
   if (nunits < 1 || nunits > 0x7fffffffLL) return -1;
   const unsigned grid = (unsigned)(nunits < ncu ? nunits : ncu);
   // (the opt-in to > 64 KB of dynamic LDS is per device: several GPUs in one process, e.g. nn.DataParallel replicas)
-  static bool attr_dev[64][3][4] = {};
+  static bool attr_dev[64][3][8] = {};
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return -2;
-  bool (&attr)[3][4] = attr_dev[dev_];
+  bool (&attr)[3][8] = attr_dev[dev_];
   if (a.pre && (version != 2 || a.res1 || a.res2 || ((a.pre_cs | a.pre_c0) & 3) || (reinterpret_cast<uintptr_t>(a.pre) & 15))) return -6;
   if (a.out2 && (a.res1 || a.pre || ((a.out2_cs | a.out2_c0) & 3) || (reinterpret_cast<uintptr_t>(a.out2) & 15))) return -6;
   if (a.out2 && version != 4 && (version != 2 || a.ntile_n != 1 || a.out2_split != 16)) return -6;
   if (a.f_w && (version != 4 || a.res1 || a.res2 || a.out2 || !a.f_bias || !a.f_scale || (reinterpret_cast<uintptr_t>(a.f_w) & 15))) return -6;
   const int res = (a.pre || a.f_w) ? 3 : a.res2 ? 2 : a.res1 ? 1 : 0;
-  const int ldsb = (version == 2) ? v2::LDS2_BYTES : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
+  // data-gradient form: plain store (+ the fused epilogue backward, 32-channel kernel only) or accumulation into `out` (res1 = out)
+  const bool sc = a.in_max != nullptr;
+  if (sc && (res > 1 || a.out2 || (version != 2 && version != 4))) return -6;
+  if (a.fb_y && (!sc || version != 2 || res != 0 || a.ntile_n != 1 || !a.fb_part || ((a.fb_y_cs | a.fb_y_c0) & 3) ||
+                 (reinterpret_cast<uintptr_t>(a.fb_y) & 15))) return -6;
+  const int ldsb = (version == 2) ? (sc ? v2::LDS2S_BYTES : v2::LDS2_BYTES) : (version == 4) ? v4::LDS4_BYTES : LDS_BYTES;
   const int vi = (version == 2) ? 1 : (version == 4) ? 2 : 0;
+  const int ai = res + (sc ? 4 : 0);
   auto go = [&](auto fn, int threads) {
-    if (!attr[vi][res]) {
+    if (!attr[vi][ai]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess) return -2;
-      attr[vi][res] = true;
+      attr[vi][ai] = true;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), ldsb, st, a, (int)nunits);
     return hipGetLastError() == hipSuccess ? 0 : -2;
   };
+  if (sc && version == 4) return res == 0 ? go(conv_wino4_kernel<0, true>, 512) : go(conv_wino4_kernel<1, true>, 512);
+  if (sc && version == 2) return res == 0 ? go(conv_wino2_kernel<0, true>, 512) : go(conv_wino2_kernel<1, true>, 512);
   if (version == 4) {
     if (res == 0) return go(conv_wino4_kernel<0>, 512);
     if (res == 1) return go(conv_wino4_kernel<1>, 512);

@@ -56,13 +56,19 @@ __device__ __forceinline__ void repack_wino_one(const RepackWinoJob& jb, int idx
     pk[o + 512] = __builtin_bit_cast(uint16_t, p1);
     return;
   }
-  if (idx >= cin * cout) return;
-  const int oc = idx / cin, ic = idx - oc * cin;
-  const int ld = jb.ld ? jb.ld : cin * 9, ld2 = jb.ld2 ? jb.ld2 : cin * 9;
-  const float* row = (!jb.w2 || oc < jb.split) ? jb.w + (size_t)oc * ld : jb.w2 + (size_t)(oc - jb.split) * ld2;
-  const int col = jb.z1_pad == 0 ? ic : (ic < jb.z1_n ? ic : ic < jb.z1_pad ? -1 : ic - jb.z1_pad + jb.z1_n);
+  const int kn = jb.tr ? jb.kn : cin;
+  if (idx >= kn * cout) return;
+  const int oc = idx / kn, ic = idx - oc * kn + (jb.tr ? jb.k0 : 0);
   float g[9];
-  for (int t = 0; t < 9; ++t) g[t] = col >= 0 ? row[(size_t)col * 9 + t] : 0.f;
+  if (jb.tr) {
+    const float* src = jb.w + (size_t)(ic - jb.k0) * jb.ld + (size_t)(jb.tr_off + oc) * 9;
+    for (int t = 0; t < 9; ++t) g[t] = src[8 - t];
+  } else {
+    const int ld = jb.ld ? jb.ld : cin * 9, ld2 = jb.ld2 ? jb.ld2 : cin * 9;
+    const float* row = (!jb.w2 || oc < jb.split) ? jb.w + (size_t)oc * ld : jb.w2 + (size_t)(oc - jb.split) * ld2;
+    const int col = jb.z1_pad == 0 ? ic : (ic < jb.z1_n ? ic : ic < jb.z1_pad ? -1 : ic - jb.z1_pad + jb.z1_n);
+    for (int t = 0; t < 9; ++t) g[t] = col >= 0 ? row[(size_t)col * 9 + t] : 0.f;
+  }
   const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
   double t[4][3], U[4][4];
   for (int i = 0; i < 4; ++i)
@@ -148,6 +154,12 @@ static int wino_ncu() {
   }
   return ncu_dev[dev];
 }
+// blocks of a launch of the 32- (ntile_n = 1) / 64-channel (2) kernel = rows of partial sums its fused epilogue backward leaves
+int conv_wino_grid(int B, int H, int W, int ntile_n) {
+  const long long nunits = (ntile_n == 2) ? (long long)B * ((W + 31) / 32) * ((H + 7) / 8) : (long long)B * ((W + 31) / 32) * ((H + 15) / 16);
+  const int ncu = wino_ncu();
+  return (int)(nunits < ncu ? nunits : ncu);
+}
 bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n) {
   const int ncu = wino_ncu();
   const long long nunits = (ntile_n == 2) ? (long long)B * ((W + 31) / 32) * ((H + 7) / 8) : (long long)B * ((W + 31) / 32) * ((H + 15) / 16);
@@ -156,7 +168,7 @@ bool conv_wino_rounds_ok(int B, int H, int W, int ntile_n) {
 }
 
 int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) {
-  if (!wpack_wino || a.nsrc < 1 || a.nsrc > 3 || a.w2 || a.tC > 0 || a.in_max) return HCF_ERR_UNSUPPORTED;
+  if (!wpack_wino || a.nsrc < 1 || a.nsrc > 3 || a.w2 || a.tC > 0) return HCF_ERR_UNSUPPORTED;
   wino::Args w;
   memset(&w, 0, sizeof(w));
   int cin = 0;
@@ -188,6 +200,13 @@ int launch_conv_wino(const ConvArgs& a, const void* wpack_wino, hipStream_t st) 
   if (a.res2.p) {
     if (!a.res1.p || a.res1_pre) return HCF_ERR_UNSUPPORTED;
     w.res2 = a.res2.p; w.res2_cs = a.res2.cs; w.res2_c0 = a.res2.c0; w.rs2 = a.rs2;
+  }
+  // data-gradient form (bwd_conv): scaled input, optionally the producer's epilogue backward in the 32-channel kernel's epilogue
+  w.in_max = a.in_max;
+  if (a.fb_y.p) {
+    if (!a.in_max || a.fb_scale || a.fb_zy || a.fb_max2 == a.in_max || !a.fb_part || a.res1.p || a.res2.p || w.ntile_n != 1) return HCF_ERR_UNSUPPORTED;
+    w.fb_y = a.fb_y.p; w.fb_y_cs = a.fb_y.cs; w.fb_y_c0 = a.fb_y.c0; w.fb_act = a.fb_act;
+    w.fb_part = a.fb_part; w.fb_max = a.fb_max; w.fb_max2 = a.fb_max2;
   }
   w.ovf = a.ovf;
   w.zeros = reinterpret_cast<const char*>(a.zeros);

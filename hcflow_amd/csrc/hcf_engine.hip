@@ -112,7 +112,8 @@ struct Step {
 // gt[m] (training): GATHER-form data-gradient pack of the block's tensor x_m (m = 0: the block input, m >= 1: growth tensor m):
 // dL/dx_m = conv3x3 over cat(dL/dpre of conv m+1 .. conv 4 (gc channels each), dL/dpre of conv 5 (nf)) with the transposed,
 // tap-flipped slices of those convs' weights -- one launch with K = (4 - m) gc + nf instead of one short-K launch per (conv, window).
-struct Rdb { Conv c[5]; Conv ca[2], cb[2]; bool fat[2] = {false, false}; Conv::TPack gt[5]; bool gather = false; };
+struct Rdb { Conv c[5]; Conv ca[2], cb[2]; bool fat[2] = {false, false}; Conv::TPack gt[5]; bool gather = false;
+             float* gtw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };      // gtw: the gather packs in Winograd form (hcf_engine_train.inc)
 struct Rrdb { Rdb r[3]; };
 
 struct CondFlow {

@@ -688,6 +688,61 @@ def test_fused_epilogue_backward_in_the_gather_convs_equals_the_separate_kernel(
     assert ndiff > 0                                      # the knob did select another summation order
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_winograd_gather_data_gradients_equal_the_direct_form(fused, monkeypatch):
+    """f16x3 training: above HCF_DGRAD_WINO_MIN_PIX pixels per map (default 64 x 64) the dense blocks' gather convs run on the Winograd
+    kernels (scaled split of the transformed gradients, the producer's epilogue backward in the 32-channel kernel's epilogue,
+    hcf_conv_wino.h SC variants; transposed packs rebuilt on the device after optimiser steps). Same sums, another order: against
+    the direct scaled kernel on the same steps (knob read at the start of each backward pass), with and without the fused epilogue
+    backward, before and after an optimiser step; the Winograd form is reproducible run to run."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, spec_grads
+    cfg = preset("SR_4X_tiny")
+    g = torch.Generator().manual_seed(29)
+    hr = torch.rand(3, 3, 96, 160, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    if fused:
+        monkeypatch.delenv("HCF_NO_EPI_FUSE", raising=False)
+    else:
+        monkeypatch.setenv("HCF_NO_EPI_FUSE", "1")
+    res = {}
+    for form, minpix in (("wino", "0"), ("direct", "1000000000")):
+        monkeypatch.setenv("HCF_DGRAD_WINO_MIN_PIX", minpix)
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(cached_params("SR_4X_tiny", 11), strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to("cuda:0").train().set_precision("f16x3")
+        opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=1e-7)
+        steps = []
+        for it in range(2):
+            for rep in range(2):                           # the same step twice: reproducible
+                opt.zero_grad(set_to_none=True)
+                _, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+                nll.backward()
+                steps.append((float(nll.detach()), spec_grads(net, cfg)))
+            assert net.engine().fallback_count() == 0
+            opt.step()
+        res[form] = steps
+    for k in (0, 2):
+        for a, b in zip(res["wino"][k][1], res["wino"][k + 1][1]):
+            assert np.array_equal(a, b)
+    ndiff = 0
+    for k in (0, 2):                                       # step 1 (host-built packs), step 2 (device refresh)
+        (n0, g0), (n1, g1) = res["wino"][k], res["direct"][k]
+        assert n0 == n1
+        gmax = max(float(np.abs(x).max()) for x in g1)
+        for a, b in zip(g0, g1):
+            assert np.isfinite(a).all()
+            ndiff += int(not np.array_equal(a, b))
+            assert float(np.abs(a - b).max()) <= 2e-4 * max(float(np.abs(b).max()), 2e-5 * gmax)
+    assert ndiff > 0                                       # the knob did select another kernel
+
+
 def test_training_step_on_a_side_stream_equals_the_default_stream():
     """The backward pass spreads over the caller's stream and the engine's own streams (weight gradients; the data gradients into the
     conditional features), tied together by events on whatever stream the caller is on: a step inside torch.cuda.stream(side) gives
