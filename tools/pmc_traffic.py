@@ -20,7 +20,7 @@ FETCH_FIX = 2.0        # gfx950: 128-B read requests are tallied as 64 B
 
 
 def short_name(k):
-    m = re.search(r"conv_f16x3_kernel<(\d), (true|false), (true|false), (true|false), (\d+), (\d+)(?:, (?:true|false))?>", k)
+    m = re.search(r"conv_f16x3_kernel<(\d), (true|false), (true|false), (true|false), (\d+), (\d+)(?:, (?:true|false))*>", k)
     if m:
         ntb, vec, up, fuse2, tailc, th = m.groups()
         tag = "f16x3<%s>" % ntb
@@ -34,10 +34,10 @@ def short_name(k):
     m = re.search(r"fcn12_kernel<(true|false)>", k)
     if m:
         return "fcn12" + ("+pre" if m.group(1) == "true" else "")
-    m = re.search(r"conv_wino4_kernel<(\d)>", k)
+    m = re.search(r"conv_wino4_kernel<(\d)(?:, false)?>", k)      # (<RES, true>: the training pass' scaled variants, not part of these tables)
     if m:
         return "wino4<%s>" % m.group(1)         # the 64-output-channel Winograd kernel (RDB conv5: 1 or 2 residual inputs)
-    m = re.search(r"conv_wino2_kernel<(\d)>", k)
+    m = re.search(r"conv_wino2_kernel<(\d)(?:, false)?>", k)
     if m:
         return "wino<%s>" % m.group(1)          # template argument = number of residual inputs (0: conv3 / conv4, 1 / 2: conv5)
     m = re.search(r"conv_mfma_kernel<(\d), (\d), (true|false)>", k)
