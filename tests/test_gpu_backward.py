@@ -743,6 +743,55 @@ def test_winograd_gather_data_gradients_equal_the_direct_form(fused, monkeypatch
     assert ndiff > 0                                       # the knob did select another kernel
 
 
+def test_taped_forward_on_the_fat_schedule_equals_the_per_conv_schedule(monkeypatch):
+    """The taped forward of a training pass runs its dense blocks as the inference pass does (run_rdb: conv 2j+1 + the old-input part
+    of conv 2j+2 as one 64-wide launch, then the completion), and records one tape entry per conv: the same tensors in another
+    summation order. Against HCF_NO_TAPE_FAT=1 (one launch per conv, read at the start of each training pass): nll, LR^ and every
+    gradient, before and after an optimiser step (the fat packs are rebuilt on the device)."""
+    import numpy as np
+    from hcflow_amd import HCFlowNet_SR
+    from hcflow_amd.config import preset
+    from tests.util import cached_params, spec_grads
+    cfg = preset("SR_4X_tiny")
+    g = torch.Generator().manual_seed(37)
+    hr = torch.rand(3, 3, 96, 160, generator=g).cuda()
+    lr = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+    noise = torch.rand(hr.shape, generator=g).cuda()
+    res = {}
+    for form in ("fat", "per_conv"):
+        if form == "fat":
+            monkeypatch.delenv("HCF_NO_TAPE_FAT", raising=False)
+        else:
+            monkeypatch.setenv("HCF_NO_TAPE_FAT", "1")
+        net = HCFlowNet_SR(opt=cfg.to_opt(), step=0)
+        net.load_state_dict(cached_params("SR_4X_tiny", 11), strict=True)
+        for m in net.modules():
+            if "ActNorm" in type(m).__name__:
+                m.inited = True
+        net = net.to("cuda:0").train().set_precision("f16x3")
+        opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=1e-7)
+        steps = []
+        for it in range(2):
+            opt.zero_grad(set_to_none=True)
+            lr_hat, nll = net(hr=hr, lr=lr, reverse=False, noise=noise)
+            nll.backward()
+            steps.append((float(nll.detach()), lr_hat.detach().clone(), spec_grads(net, cfg)))
+            assert net.engine().fallback_count() == 0
+            opt.step()
+        res[form] = steps
+    ndiff = 0
+    for it in range(2):
+        (n0, l0, g0), (n1, l1, g1) = res["fat"][it], res["per_conv"][it]
+        assert abs(n0 - n1) <= 1e-6 * abs(n1)
+        assert float((l0 - l1).abs().max()) <= 1e-5
+        gmax = max(float(np.abs(x).max()) for x in g1)
+        for a, b in zip(g0, g1):
+            assert np.isfinite(a).all()
+            ndiff += int(not np.array_equal(a, b))
+            assert float(np.abs(a - b).max()) <= 2e-4 * max(float(np.abs(b).max()), 2e-5 * gmax)
+    assert ndiff > 0                                       # the knob did select another schedule
+
+
 def test_training_step_on_a_side_stream_equals_the_default_stream():
     """The backward pass spreads over the caller's stream and the engine's own streams (weight gradients; the data gradients into the
     conditional features), tied together by events on whatever stream the caller is on: a step inside torch.cuda.stream(side) gives
