@@ -211,7 +211,7 @@ def main():
     import torch
     import torch.distributed as dist
     from hcflow_amd import HCFlowNet_SR, HCFlowNet_Rescaling, preset, make_params
-    from hcflow_amd.dist import gathered_step, timed_region
+    from hcflow_amd.dist import gathered_step, timed_region, gather_flush
     from hcflow_amd import _lib as _hcf_lib
     lib = _hcf_lib.load()
 
@@ -484,6 +484,7 @@ def main():
             check["quantised_lr_levels_flipped_frac"] = quant_flips
         del y_fast, y_exact
     net.set_precision(default_mode)
+    gather_flush()                                      # (N > 1: the check leg's overlapped all-gathers, before anything tears the group down)
     overflow = net.check_range()                        # the one wait for the asynchronous range flag
     if check is not None:
         check["range_overflow_in_any_pass"] = bool(overflow)
