@@ -793,7 +793,20 @@ def other_configs(dev, params_sr4, steps, mode):
         rows.sort(key=lambda r: sum(r))
         med = rows[len(rows) // 2]              # the median step (the phases are host-synchronised: one hiccup would skew a mean)
         dt = sum(med)
+        # the same steps as train_HCFlow.py's loop issues them: no synchronisation between the phases or the steps (the timing of
+        # `python bench.py --workload train`, without its DDP wrap)
+        nfree = 8
+        sync(); f0 = time.perf_counter()
+        for i in range(nfree):
+            opt.zero_grad(set_to_none=True)
+            _, nll = net(hr=hr, lr=lr, reverse=False)
+            nll.backward()
+            clip(net.parameters(), 100.0)
+            opt.step()
+        sync(); dfree = (time.perf_counter() - f0) / nfree
         return {
+            "free_running": {"ms_per_step": round(1e3 * dfree, 3), "value": round(16 / dfree, 2), "steps": nfree,
+                             "note": "no host synchronisation inside or between the steps, as the reference's training loop runs them"},
             "value": round(16 / dt, 2), "unit": "samples/s per GPU (B=16 HR 160x160; global batch 128 on 8 GPUs)",
             "higher_is_better": True, "ms_per_step": round(1e3 * dt, 3),
             "phases_ms": {"forward_incl_refresh": round(1e3 * med[0], 2), "backward": round(1e3 * med[1], 2),
@@ -802,8 +815,9 @@ def other_configs(dev, params_sr4, steps, mode):
             "mfma_frac": round(16 * GFLOP_TRAIN_SAMPLE / 1e3 / dt / peak, 4),
             "mfma_frac_forward": round(16 * (GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / med[0] / peak, 4),
             "mfma_frac_backward": round(16 * (2.0 * GFLOP_TRAIN_SAMPLE / 3.0) / 1e3 / med[1] / peak, 4),
-            "note": "phases are host-synchronised (sum of the three); the free-running step of train_HCFlow.py's loop overlaps the "
-                    "optimiser's host work with the backward pass on the GPU: `python bench.py --workload train` times that"}
+            "note": "value / ms_per_step / phases are host-synchronised (sum of the three); `free_running` is the same step as "
+                    "train_HCFlow.py's loop issues it (the optimiser's host work overlaps the backward pass on the GPU); "
+                    "`python bench.py --workload train` is that timing under the DDP wrap as a line of its own"}
     out["config5_nll_train_step"] = train_config(False)
     out["config5_nll_train_step"]["optimizer"] = "torch.optim.Adam + torch.nn.utils.clip_grad_norm_ (the reference caller's lines, unchanged)"
     try:
